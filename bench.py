@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- timesteps/s of the Cahn-Hilliard solver loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one iteration of chsimpy/solver.py:165-249 (pointwise chemical
+potential -> 2-D DCT-II -> spectral update -> inverse DCT -> energy/statistics
+record) on an N x N fp64 grid resident in HBM.  Workload at --gpus 1: BASELINE.json
+configs[2] (N=4096, fp64, synthetic U_init of solver.py:78-82 with seed 2023).
+With --gpus G > 1 every rank (one process per GPU, RCCL) advances its own
+independent member of a Monte-Carlo ensemble (chsimpy/experiment.py:84-126, one run
+per GPU, A0/A1 scaled per rank) -- weak scaling, no data-path collective; the only
+collective is the all_gather of the per-run energy scalars at the end.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+KAPPA = 0.0002989112919661156
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--grid', type=int, default=4096, help='N (default: BASELINE.json configs[2])')
+    ap.add_argument('--dtype', default='float64')
+    ap.add_argument('--engine', default='auto')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=0, help='0 = size the CPU sample automatically')
+    ap.add_argument('--profile-steps', type=int, default=20)
+    return ap.parse_args()
+
+
+def make_params(N, dtype, engine, device, rank):
+    import chsimpy_amd
+    from chsimpy_amd import utils
+    p = chsimpy_amd.Parameters()
+    p.N, p.ntmax, p.full_sim, p.kappa_tilde = N, 10 ** 9, True, KAPPA
+    p.dtype, p.engine, p.device = dtype, engine, device
+    if rank > 0:
+        # ensemble member: experiment.py:92-96 scales A0/A1 by factors from PCG64(A_seed)
+        fac = np.random.Generator(np.random.PCG64(85972)).uniform(0.995, 1.005, size=(64, 2))[rank % 64]
+        p.func_A0 = lambda temp, f=fac[0]: utils.A0(temp) * f
+        p.func_A1 = lambda temp, f=fac[1]: utils.A1(temp) * f
+    return p
+
+
+def algorithmic_bytes_per_step(N, esz):
+    """8 full-array transfers per timestep."""
+    return 8 * N * N * esz
+
+
+# Algorithmic transfers attributed to each per-step kernel slot.
+SLOT_TRANSFERS = {
+    'fast': {'k_row_fwd': 2, 'k_col': 4, 'k_row_inv': 2},
+    'direct': {},
+}
+
+
+def cpu_baseline(N, steps_hint):
+    """The oracle (numpy/scipy restatement, 1 core like chsimpy/simulator.py:14,36) on a
+    bounded sample of the same workload, timed like examples/benchmark.py:68-76."""
+    from threadpoolctl import threadpool_limits
+    from oracle import chs_oracle as orc
+    with threadpool_limits(limits=1, user_api='blas'):
+        # size the sample: ~0.3 us per grid point per step on one core
+        est = 0.45e-6 * N * N
+        steps = steps_hint or int(max(2, min(200, 20.0 / est)))
+        p = orc.make_params(N, steps + 1)
+        o = orc.OracleSolver(p)
+        o.prepare()
+        t0 = time.time()
+        o.solve_or_resume()
+        dt = time.time() - t0
+    return {'value': steps / dt, 'unit': 'timesteps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'oracle/chs_oracle.py (numpy+scipy.fftpack), N={N} fp64, {steps} timesteps after prepare(), '
+                      f'{dt:.1f} s wall, BLAS limited to 1 thread; host has {os.cpu_count()} logical cores'}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    device = local_rank if world > 1 else 0
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build_hip()
+    if dist is not None:
+        dist.barrier()
+    import chsimpy_amd
+
+    N = a.grid
+    p = make_params(N, a.dtype, a.engine, device, rank)
+    s = chsimpy_amd.Solver(p)
+    s.prepare()
+    eng = s._engine
+    esz = 8 if a.dtype in ('float64', 'f64') else 4
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # warmup (untimed).  The first call after prepare() runs nsteps-1 iterations
+    # (solver.py:160-165), so ask for one more.
+    s.solve_or_resume(a.warmup + 1)
+    # keep the input resident: nothing is uploaded inside the timed region; the
+    # entry transform hat_U = dctn(U) of solve_or_resume (solver.py:159) is part of it.
+    sync()
+    t0 = time.perf_counter()
+    rows, rc = eng.step_n(a.steps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    assert rows.shape[0] == a.steps and rc == 0, (rows.shape, rc)
+    dt = t1 - t0
+    dev_ms = eng.last_step_ms()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # the ensemble's only collective: gather the per-run energy scalars (E, E2 of the last step)
+        mine = torch.tensor([float(rows[-1, 1]), float(rows[-1, 2])], dtype=torch.float64, device='cuda')
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        energies = [[float(v[0]), float(v[1])] for v in allv]
+    else:
+        energies = [[float(rows[-1, 1]), float(rows[-1, 2])]]
+
+    out = None
+    if rank == 0:
+        value = world * a.steps / dt
+        ms_per_step = dt * 1e3 / a.steps
+        bytes_step = algorithmic_bytes_per_step(N, esz)
+        # dominant kernel, HIP events on the engine's stream
+        ms, calls = eng.profile_steps(a.profile_steps)
+        names = eng.kernel_names()
+        per = {names[i]: ms[i] / calls[i] for i in range(len(names)) if names[i] and calls[i] > 0}
+        dom = max(per, key=per.get)
+        transfers = SLOT_TRANSFERS.get(eng.engine, {}).get(dom)
+        if transfers is None:
+            # kernels outside the 8-transfer model: price them with the whole-step figure
+            dom_bytes = None
+            achieved = bytes_step / (sum(per.values()) * 1e-3) / 1e9
+        else:
+            dom_bytes = transfers * N * N * esz
+            achieved = dom_bytes / (per[dom] * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(f'{eng.engine}:{dom}:N{N}')
+            except Exception:
+                traffic = None
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'algorithmic_bytes_per_launch': dom_bytes,
+                    'avg_launch_ms': round(per[dom], 5),
+                    'kernel_ms': {k: round(v, 5) for k, v in per.items()},
+                    'whole_step': {'algorithmic_bytes': bytes_step,
+                                   'achieved': round(bytes_step / (ms_per_step * 1e-3) / 1e9, 1),
+                                   'frac': round(bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        out = {
+            'metric': 'timesteps/sec at N=4096 fp64; achieved HBM GB/s vs MI355X peak',
+            'value': round(value, 3), 'unit': 'timesteps/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64' if esz == 8 else 'f32', 'data': 'synthetic',
+            'config': {'workload': f'N={N} {"fp64" if esz == 8 else "fp32"} Cahn-Hilliard timestep loop '
+                                   f'(BASELINE.json configs[2] at N=4096), U_init = 0.875 + 0.00875*(PCG64(2023).random - 0.5), '
+                                   f'kappa_tilde={KAPPA}, full_sim',
+                       'N': N, 'engine': eng.engine,
+                       'ensemble': f'{world} independent run(s), one per GPU' if world > 1 else 'single run',
+                       'device_ms_per_step': round(dev_ms / a.steps, 5)},
+            'roofline': roofline,
+            'energies_last_step': energies,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(N, a.cpu_steps)
+        elif world == 1:
+            out['cpu_baseline'] = None
+    s.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

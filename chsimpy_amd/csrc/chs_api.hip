@@ -1,0 +1,420 @@
+// chs_api.hip -- the C ABI of include/chs_hip.h: handle lifetime, host<->device
+// traffic and the per-timestep launch sequence (chsimpy/solver.py:84-252).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "chs_common.h"
+
+static thread_local std::string g_err;
+
+void chs_set_error(const std::string& s) { g_err = s; }
+int chs_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file, line, what);
+  g_err = buf;
+  return CHS_EHIP;
+}
+extern "C" const char* chs_last_error(void) { return g_err.c_str(); }
+extern "C" const char* chs_version(void) { return "chsimpy_amd 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------
+// kernel-slot timing (chs_profile_steps)
+// ---------------------------------------------------------------------------
+static hipEvent_t timer_event(StepTimer& t) {
+  if (!t.pool.empty()) { hipEvent_t e = t.pool.back(); t.pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+void chs_slot_begin(Engine* E, int slot) {
+  (void)slot;
+  if (!E->timer.on) return;
+  E->timer.cur = timer_event(E->timer);
+  hipEventRecord(E->timer.cur, E->stream);
+}
+void chs_slot_end(Engine* E, int slot) {
+  if (!E->timer.on) return;
+  hipEvent_t b = timer_event(E->timer);
+  hipEventRecord(b, E->stream);
+  E->timer.pending.push_back({slot, E->timer.cur, b});
+  E->timer.cur = nullptr;
+}
+static void timer_harvest(Engine* E) {
+  hipStreamSynchronize(E->stream);
+  for (auto& s : E->timer.pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      E->timer.ms[s.slot] += ms;
+      E->timer.calls[s.slot] += 1;
+    }
+    E->timer.pool.push_back(s.a);
+    E->timer.pool.push_back(s.b);
+  }
+  E->timer.pending.clear();
+}
+
+// ---------------------------------------------------------------------------
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+static int ensure_rows(Engine* E, long long n) {
+  if (n < 1) n = 1;
+  if (n <= E->rowsCap) return CHS_OK;
+  if (E->dRows) hipFree(E->dRows);
+  E->dRows = nullptr;
+  CHS_HIP(hipMalloc(&E->dRows, sizeof(double) * 9 * (size_t)n));
+  E->rowsCap = n;
+  return CHS_OK;
+}
+
+static void free_engine(Engine* E) {
+  if (!E) return;
+  hipSetDevice(E->hc.device);
+  if (E->engine == CHS_ENGINE_DIRECT) chs_direct_free(E);
+  if (E->engine == CHS_ENGINE_FAST) chs_fast_free(E);
+  chs_pointwise_free(E);
+  hipFree(E->dU); hipFree(E->dMU); hipFree(E->dT1); hipFree(E->dT2); hipFree(E->dHat);
+  hipFree(E->dNoise); hipFree(E->dLambda); hipFree(E->dState); hipFree(E->dRows);
+  for (auto e : E->timer.pool) hipEventDestroy(e);
+  if (E->evA) hipEventDestroy(E->evA);
+  if (E->evB) hipEventDestroy(E->evB);
+  if (E->stream) hipStreamDestroy(E->stream);
+  delete E;
+}
+
+extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle* out) {
+  if (!c || !lambda || !out) { chs_set_error("chs_create: null argument"); return CHS_EINVAL; }
+  *out = nullptr;
+  if (c->N < 8 || c->N > 16384) { chs_set_error("chs_create: N must be in [8, 16384]"); return CHS_EINVAL; }
+  if (c->dtype != CHS_F64 && c->dtype != CHS_F32) { chs_set_error("chs_create: bad dtype"); return CHS_EINVAL; }
+  int ndev = 0;
+  CHS_HIP(hipGetDeviceCount(&ndev));
+  if (c->device < 0 || c->device >= ndev) {
+    chs_set_error("chs_create: no such HIP device (the engine needs a GPU; there is no CPU fallback)");
+    return CHS_EINVAL;
+  }
+  CHS_HIP(hipSetDevice(c->device));
+  Engine* E = new (std::nothrow) Engine();
+  if (!E) { chs_set_error("out of host memory"); return CHS_EINVAL; }
+  E->hc = *c;
+  E->N = c->N;
+  E->dtype = c->dtype;
+  E->esz = (c->dtype == CHS_F64) ? 8 : 4;
+  const int N = c->N;
+  int eng = c->engine;
+  if (eng == CHS_ENGINE_AUTO) eng = chs_fast_supported(N, c->dtype) ? CHS_ENGINE_FAST : CHS_ENGINE_DIRECT;
+  if (eng == CHS_ENGINE_FAST && !chs_fast_supported(N, c->dtype)) {
+    delete E;
+    chs_set_error("chs_create: the fast engine needs N = power of two in [128, 8192]");
+    return CHS_EINVAL;
+  }
+  if (eng != CHS_ENGINE_FAST && eng != CHS_ENGINE_DIRECT) { delete E; chs_set_error("bad engine"); return CHS_EINVAL; }
+  E->engine = eng;
+  DevConsts& d = E->dc;
+  memset(&d, 0, sizeof d);
+  d.N = N; d.adaptive_time = c->adaptive_time; d.full_sim = c->full_sim;
+  d.RT = c->RT; d.BRT = c->BRT; d.B = c->B; d.A0 = c->A0; d.A1 = c->A1; d.Amr = c->Amr;
+  d.kappa_tilde = c->kappa_tilde; d.L = c->L; d.delx = c->delx;
+  d.delx2 = c->delx * c->delx;  // solution.py:29 `self.delx ** 2`
+  d.delt0 = c->delt; d.delt_max = c->delt_max; d.M_tilde = c->M_tilde; d.threshold = c->threshold;
+  d.time_limit_s = c->time_limit_s;
+  d.invN2 = 1.0 / ((double)N * (double)N);
+
+  int rc = CHS_OK;
+  auto fail = [&](int code) { free_engine(E); return code; };
+#define TRY_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { chs_hip_fail(e__, #call, __FILE__, __LINE__); return fail(CHS_EHIP); } } while (0)
+  TRY_HIP(hipStreamCreateWithFlags(&E->stream, hipStreamNonBlocking));
+  TRY_HIP(hipEventCreate(&E->evA));
+  TRY_HIP(hipEventCreate(&E->evB));
+  const size_t nb = (size_t)N * N * E->esz;
+  TRY_HIP(hipMalloc(&E->dU, nb));
+  TRY_HIP(hipMalloc(&E->dMU, nb));
+  TRY_HIP(hipMalloc(&E->dT1, nb));
+  TRY_HIP(hipMalloc(&E->dT2, nb));
+  TRY_HIP(hipMalloc(&E->dHat, nb));
+  TRY_HIP(hipMalloc(&E->dLambda, sizeof(double) * N));
+  TRY_HIP(hipMemcpy(E->dLambda, lambda, sizeof(double) * N, hipMemcpyHostToDevice));
+  TRY_HIP(hipMalloc(&E->dState, sizeof(DevState)));
+  DevState s0;
+  memset(&s0, 0, sizeof s0);
+  s0.delt = c->delt;
+  s0.lam1 = c->delt / d.delx2;
+  s0.lam2 = c->kappa_tilde * s0.lam1 / d.delx2;
+  TRY_HIP(hipMemcpy(E->dState, &s0, sizeof s0, hipMemcpyHostToDevice));
+  if ((rc = ensure_rows(E, 64))) return fail(rc);
+  if ((rc = chs_pointwise_alloc(E))) return fail(rc);
+  if (eng == CHS_ENGINE_DIRECT) rc = chs_direct_init(E); else rc = chs_fast_init(E);
+  if (rc) return fail(rc);
+#undef TRY_HIP
+  *out = (chs_handle)E;
+  return CHS_OK;
+}
+
+extern "C" int chs_destroy(chs_handle h) {
+  free_engine((Engine*)h);
+  return CHS_OK;
+}
+
+extern "C" int chs_engine(chs_handle h) { return h ? ((Engine*)h)->engine : CHS_EINVAL; }
+
+static int upload(Engine* E, void* dst, const double* src) {
+  const size_t n = (size_t)E->N * E->N;
+  if (E->dtype == CHS_F64) {
+    CHS_HIP(hipMemcpy(dst, src, n * 8, hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+    CHS_HIP(hipMemcpy(dst, tmp.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  return CHS_OK;
+}
+static int download(Engine* E, double* dst, const void* src) {
+  const size_t n = (size_t)E->N * E->N;
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  if (E->dtype == CHS_F64) {
+    CHS_HIP(hipMemcpy(dst, src, n * 8, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<float> tmp(n);
+    CHS_HIP(hipMemcpy(tmp.data(), src, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) dst[i] = (double)tmp[i];
+  }
+  return CHS_OK;
+}
+
+extern "C" int chs_set_U(chs_handle h, const double* host_U) {
+  Engine* E = (Engine*)h;
+  if (!E || !host_U) { chs_set_error("chs_set_U: null argument"); return CHS_EINVAL; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  int rc = upload(E, E->dU, host_U);
+  if (rc) return rc;
+  E->have_U = true;
+  E->hat_valid = false;
+  return CHS_OK;
+}
+
+extern "C" int chs_get_U(chs_handle h, double* host_U) {
+  Engine* E = (Engine*)h;
+  if (!E || !host_U) { chs_set_error("chs_get_U: null argument"); return CHS_EINVAL; }
+  if (!E->have_U) { chs_set_error("chs_get_U: no field uploaded"); return CHS_ESTATE; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  return download(E, host_U, E->dU);
+}
+
+extern "C" int chs_get_state(chs_handle h, chs_state* out) {
+  Engine* E = (Engine*)h;
+  if (!E || !out) { chs_set_error("chs_get_state: null argument"); return CHS_EINVAL; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  DevState s;
+  CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+  out->delt = s.delt; out->time_delta_sum = s.time_delta_sum; out->time_passed = s.time_passed;
+  out->tau0 = s.tau0; out->t0 = s.t0; out->computed_steps = s.computed_steps;
+  out->skip_check = s.skip_check; out->stop_reason = s.stop_reason;
+  return CHS_OK;
+}
+
+extern "C" int chs_set_state(chs_handle h, const chs_state* in) {
+  Engine* E = (Engine*)h;
+  if (!E || !in) { chs_set_error("chs_set_state: null argument"); return CHS_EINVAL; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  DevState s;
+  CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+  s.delt = in->delt; s.time_delta_sum = in->time_delta_sum; s.time_passed = in->time_passed;
+  s.tau0 = in->tau0; s.t0 = in->t0; s.computed_steps = in->computed_steps;
+  s.skip_check = in->skip_check; s.stop_reason = in->stop_reason;
+  s.lam1 = s.delt / E->dc.delx2;
+  s.lam2 = E->dc.kappa_tilde * s.lam1 / E->dc.delx2;
+  CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
+  return CHS_OK;
+}
+
+// solver.py:84-135
+extern "C" int chs_prepare(chs_handle h, double row0[9]) {
+  Engine* E = (Engine*)h;
+  if (!E || !row0) { chs_set_error("chs_prepare: null argument"); return CHS_EINVAL; }
+  if (!E->have_U) { chs_set_error("chs_prepare: chs_set_U first"); return CHS_ESTATE; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  int rc;
+  if ((rc = chs_launch_sum(E, 1))) return rc;
+  if ((rc = chs_launch_diag(E, 1))) return rc;
+  if ((rc = chs_launch_fin(E, 1))) return rc;
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  CHS_HIP(hipMemcpy(row0, E->dRows, sizeof(double) * 9, hipMemcpyDeviceToHost));
+  E->prepared = true;
+  for (int i = 0; i < 9; ++i)
+    if (row0[i] != row0[i]) { chs_set_error("chs_prepare: NaN in the step-0 record (timedata.py:10)"); return CHS_ENAN; }
+  return CHS_OK;
+}
+
+// hat_U <- dctn(U), solver.py:159
+static int enter(Engine* E) {
+  if (E->engine == CHS_ENGINE_DIRECT) return chs_direct_dct2d(E, E->dU, E->dHat, E->dT1, false);
+  return chs_fast_enter(E);
+}
+
+// one iteration of solver.py:165-249
+static int one_step(Engine* E) {
+  int rc;
+  if (E->engine == CHS_ENGINE_DIRECT) {
+    if ((rc = chs_launch_mu(E))) return rc;        // 166-175
+    if ((rc = chs_launch_pre(E))) return rc;       // 177-199, 225
+    chs_slot_begin(E, SLOT_FWD);
+    rc = chs_direct_dct2d(E, E->dMU, E->dT2, E->dT1, false);  // dctn(EnergieEut), 201
+    chs_slot_end(E, SLOT_FWD);
+    if (rc) return rc;
+    if ((rc = chs_launch_spectral(E, E->dT2))) return rc;      // 201-206
+    chs_slot_begin(E, SLOT_INV);
+    rc = chs_direct_dct2d(E, E->dHat, E->dU, E->dT1, true);   // 208
+    chs_slot_end(E, SLOT_INV);
+    if (rc) return rc;
+  } else {
+    if ((rc = chs_fast_step(E))) return rc;
+  }
+  if (E->dNoise && E->jitter > 0.0 && E->jitter < 0.1) {        // 210-211
+    if ((rc = chs_launch_jitter(E))) return rc;
+    if ((rc = chs_launch_sum(E, 0))) return rc;
+  }
+  if ((rc = chs_launch_diag(E, 0))) return rc;     // 213-228
+  if ((rc = chs_launch_fin(E, 0))) return rc;      // 230-249
+  return CHS_OK;
+}
+
+static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t* steps_done, bool profile) {
+  if (!E->prepared) { chs_set_error("chs_step_n: not prepared (solver.py:139)"); return CHS_ESTATE; }
+  if (nsteps < 0) nsteps = 0;
+  CHS_HIP(hipSetDevice(E->hc.device));
+  int rc;
+  if ((rc = ensure_rows(E, nsteps))) return rc;
+  // a new call re-arms the loop: `halt` only lives inside one solve_or_resume
+  {
+    DevState s;
+    CHS_HIP(hipStreamSynchronize(E->stream));
+    CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+    s.halt = 0; s.nan_flag = 0; s.rows_written = 0;
+    CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
+  }
+  if (profile) {
+    E->timer.on = true;
+    for (int i = 0; i < CHS_NKERNELS; ++i) { E->timer.ms[i] = 0; E->timer.calls[i] = 0; }
+  }
+  CHS_HIP(hipEventRecord(E->evA, E->stream));
+  E->timer.on = false;  // the entry transform is not a per-step kernel
+  if (!((flags & CHS_STEP_CARRY_HAT) && E->hat_valid)) {
+    if ((rc = enter(E))) return rc;
+  }
+  E->hat_valid = true;
+  E->timer.on = profile;
+  for (int64_t s = 0; s < nsteps; ++s) {
+    if ((rc = one_step(E))) { E->timer.on = false; return rc; }
+    if (profile && (s % 32) == 31) timer_harvest(E);
+  }
+  if (profile) { timer_harvest(E); E->timer.on = false; }
+  CHS_HIP(hipEventRecord(E->evB, E->stream));
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  float ms = 0.f;
+  CHS_HIP(hipEventElapsedTime(&ms, E->evA, E->evB));
+  E->lastStepMs = ms;
+  DevState s;
+  CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+  int64_t done = s.rows_written;
+  if (done > nsteps) done = nsteps;
+  if (steps_done) *steps_done = done;
+  if (rows && done > 0) {
+    CHS_HIP(hipMemcpy(rows, E->dRows, sizeof(double) * 9 * (size_t)done, hipMemcpyDeviceToHost));
+    // solver.py:230 `domtime = self.time_passed ** (1 / 3)` with the host libm
+    for (int64_t i = 0; i < done; ++i) rows[i * 9 + 4] = pow(rows[i * 9 + 4], 1.0 / 3.0);
+  }
+  if (s.nan_flag) {
+    chs_set_error("NaN in a recorded scalar (timedata.py:10): U left (0,1)");
+    return CHS_ENAN;
+  }
+  return CHS_OK;
+}
+
+extern "C" int chs_step_n(chs_handle h, int64_t nsteps, int32_t flags, double* rows, int64_t* steps_done) {
+  Engine* E = (Engine*)h;
+  if (!E) { chs_set_error("chs_step_n: null handle"); return CHS_EINVAL; }
+  if (nsteps > 0 && !rows) { chs_set_error("chs_step_n: rows is null"); return CHS_EINVAL; }
+  return run_steps(E, nsteps, flags, rows, steps_done, false);
+}
+
+extern "C" int chs_profile_steps(chs_handle h, int64_t nsteps, double ms[CHS_NKERNELS], int64_t calls[CHS_NKERNELS]) {
+  Engine* E = (Engine*)h;
+  if (!E || !ms || !calls) { chs_set_error("chs_profile_steps: null argument"); return CHS_EINVAL; }
+  std::vector<double> rows((size_t)(nsteps > 0 ? nsteps : 1) * 9);
+  int64_t done = 0;
+  int rc = run_steps(E, nsteps, 0, rows.data(), &done, true);
+  for (int i = 0; i < CHS_NKERNELS; ++i) { ms[i] = E->timer.ms[i]; calls[i] = E->timer.calls[i]; }
+  return rc;
+}
+
+extern "C" double chs_last_step_ms(chs_handle h) { return h ? ((Engine*)h)->lastStepMs : -1.0; }
+
+extern "C" const char* chs_kernel_name(chs_handle h, int slot) {
+  Engine* E = (Engine*)h;
+  if (!E || slot < 0 || slot >= CHS_NKERNELS) return nullptr;
+  static const char* direct[CHS_NKERNELS] = {"k_mu", "k_pre", "k_gemm x2 (dctn)", "k_spectral", "k_gemm x2 (idctn)",
+                                             "k_diag", "k_fin", "misc"};
+  static const char* fast[CHS_NKERNELS] = {"k_row_fwd", "k_pre", nullptr, "k_col", "k_row_inv",
+                                           "k_diag", "k_fin", "misc"};
+  return E->engine == CHS_ENGINE_DIRECT ? direct[slot] : fast[slot];
+}
+
+extern "C" int chs_set_jitter_noise(chs_handle h, double jitter, const double* host_noise) {
+  Engine* E = (Engine*)h;
+  if (!E) { chs_set_error("chs_set_jitter_noise: null handle"); return CHS_EINVAL; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  E->jitter = jitter;
+  if (!host_noise) {  // switch jitter off
+    if (E->dNoise) { hipFree(E->dNoise); E->dNoise = nullptr; }
+    return CHS_OK;
+  }
+  if (!E->dNoise) CHS_HIP(hipMalloc(&E->dNoise, (size_t)E->N * E->N * E->esz));
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  return upload(E, E->dNoise, host_noise);
+}
+
+extern "C" int chs_dctn(chs_handle h, const double* host_in, double* host_out, int inverse) {
+  Engine* E = (Engine*)h;
+  if (!E || !host_in || !host_out) { chs_set_error("chs_dctn: null argument"); return CHS_EINVAL; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  // dMU/dT2 are scratch between steps
+  int rc = upload(E, E->dMU, host_in);
+  if (rc) return rc;
+  // make sure a stale halt flag does not turn the transform into a no-op
+  DevState s;
+  CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+  const int halt = s.halt;
+  s.halt = 0;
+  CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
+  if (E->engine == CHS_ENGINE_DIRECT) rc = chs_direct_dct2d(E, E->dMU, E->dT2, E->dT1, inverse != 0);
+  else rc = chs_fast_dct2d(E, E->dMU, E->dT2, inverse != 0);
+  if (rc) return rc;
+  rc = download(E, host_out, E->dT2);
+  s.halt = halt;
+  CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
+  return rc;
+}
+
+extern "C" int chs_get_mu(chs_handle h, double* host_mu) {
+  Engine* E = (Engine*)h;
+  if (!E || !host_mu) { chs_set_error("chs_get_mu: null argument"); return CHS_EINVAL; }
+  if (!E->have_U) { chs_set_error("chs_get_mu: no field uploaded"); return CHS_ESTATE; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  DevState s;
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+  const int halt = s.halt;
+  s.halt = 0;
+  CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
+  int rc = chs_launch_mu(E);
+  if (rc) return rc;
+  rc = download(E, host_mu, E->dMU);
+  s.halt = halt;
+  CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
+  return rc;
+}

@@ -1,0 +1,190 @@
+// chs_common.h -- internal declarations shared by the HIP translation units.
+// gfx950 (MI355X) only: 64-wide wavefronts are assumed throughout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "chs_hip.h"
+
+#define CHS_WAVE 64
+
+// ---------------------------------------------------------------------------
+// Device-resident scalar state of one simulation: what chsimpy/solver.py keeps
+// in `self.*` / `self.solution.*` between iterations, plus the reduction
+// results handed from one kernel of a step to the next.
+// ---------------------------------------------------------------------------
+struct DevState {
+  double delt;            // solver.py:54,185-188
+  double time_delta_sum;  // solver.py:51,195
+  double time_passed;     // solver.py:52,196
+  double tau0, t0;        // solver.py:243-244
+  double E2_0, E2_prev;   // timedata.py:63 operands
+  double L2_cur;          // ||EnergieEut||_F / N^2 of the running step (solver.py:225)
+  double meanU;           // mean of the field the next statistics sweep refers to (solver.py:223)
+  double lam1, lam2;      // utils.py:41-42 for the current delt
+  long long computed_steps;  // solver.py:134,240
+  long long rows_written;    // rows produced by the running chs_step_n call
+  int skip_check;            // solver.py:50,249
+  int stop_reason;           // CHS_STOP_*
+  int nan_flag;              // timedata.py:10
+  int halt;                  // != 0: every later kernel of the call is a no-op
+};
+
+// Read-only scalars, passed to kernels by value.
+struct DevConsts {
+  int N;
+  int adaptive_time;
+  int full_sim;
+  int pad_;
+  double RT, BRT, B, A0, A1, Amr, kappa_tilde, L, delx, delx2;
+  double delt0;  // params.delt (lower bound of the adaptive step, solver.py:184)
+  double delt_max, M_tilde, threshold, time_limit_s;
+  double invN2;  // 1/N^2
+};
+
+// ---------------------------------------------------------------------------
+// Deterministic block reductions (fixed tree: DPP/shuffle inside a wave, LDS
+// across waves).  Callers pass a __shared__ scratch of >= 32 doubles.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+  return v;
+}
+// Returns the block total in every thread.  All threads of the block must call.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < nw; ++w) t += scratch[w];
+  return t;
+}
+__device__ __forceinline__ double block_min(double v, double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_min(v);
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  double t = scratch[0];
+  for (int w = 1; w < nw; ++w) t = fmin(t, scratch[w]);
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// Host-side engine object behind chs_handle.
+// ---------------------------------------------------------------------------
+struct Engine;
+
+// Per-step kernel slots for chs_profile_steps / chs_kernel_name.
+struct StepTimer {
+  bool on = false;
+  double ms[CHS_NKERNELS];
+  long long calls[CHS_NKERNELS];
+  struct Span { int slot; hipEvent_t a, b; };
+  std::vector<Span> pending;     // recorded, not yet harvested
+  std::vector<hipEvent_t> pool;  // free events
+  hipEvent_t cur = nullptr;      // start event of the open span
+};
+
+struct Engine {
+  chs_consts hc;       // as given
+  DevConsts dc;        // device view
+  int engine = 0;      // resolved CHS_ENGINE_*
+  int N = 0;
+  int dtype = CHS_F64;
+  size_t esz = 8;
+  hipStream_t stream = nullptr;
+  bool prepared = false;
+  bool have_U = false;
+  bool hat_valid = false;  // dHat matches dU's history (CHS_STEP_CARRY_HAT)
+
+  // device buffers (element type per dtype)
+  void* dU = nullptr;      // field U, row-major N x N
+  void* dMU = nullptr;     // EnergieEut (direct engine) / scratch
+  void* dT1 = nullptr;     // transform scratch
+  void* dT2 = nullptr;     // transform scratch
+  void* dHat = nullptr;    // hat_U (direct: natural order; fast: engine-native order)
+  void* dNoise = nullptr;  // jitter noise (optional)
+  double jitter = 0.0;
+  double* dLambda = nullptr;   // lam_i, N doubles
+  void* dD = nullptr;          // direct engine: orthonormal DCT-II matrix D[k][n]
+  void* dTw = nullptr;         // fast engine: twiddle tables
+  DevState* dState = nullptr;
+  double* dRows = nullptr;     // timedata rows of the running call
+  long long rowsCap = 0;
+  double* dPartMu = nullptr;   // per-block sum(mu^2)
+  double* dPartCol = nullptr;  // per-band column sums for the adaptive step
+  double* dPartColMin = nullptr;
+  double* dPartDiag = nullptr; // per-block [sE, sG, sPS, cSA]
+  double* dPartSum = nullptr;  // per-block sum(U)
+  int nBands = 0;              // row bands used by the pointwise kernels
+  int nDiagBlocks = 0;
+  int nColMinBlocks = 0;
+
+  hipEvent_t evA = nullptr, evB = nullptr;
+  double lastStepMs = 0.0;
+  StepTimer timer;
+  std::vector<double> hostTmp;
+};
+
+void chs_set_error(const std::string& s);
+int chs_hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define CHS_HIP(call)                                                    \
+  do {                                                                   \
+    hipError_t e__ = (call);                                             \
+    if (e__ != hipSuccess) return chs_hip_fail(e__, #call, __FILE__, __LINE__); \
+  } while (0)
+
+// kernel-slot bracket used by the launchers
+void chs_slot_begin(Engine* E, int slot);
+void chs_slot_end(Engine* E, int slot);
+
+// slots
+enum {
+  SLOT_MU = 0,      // direct: pointwise EnergieEut           | fast: row pass forward (mu + DCT-II rows)
+  SLOT_PRE = 1,     // k_pre (+ k_colmin): L2, adaptive dt, time bookkeeping
+  SLOT_FWD = 2,     // direct: the two forward products       | fast: (unused)
+  SLOT_SPEC = 3,    // direct: spectral update                | fast: column pass (DCT-II, update, DCT-III)
+  SLOT_INV = 4,     // direct: the two inverse products       | fast: row pass inverse (DCT-III rows)
+  SLOT_DIAG = 5,    // energy / statistics sweep
+  SLOT_FIN = 6,     // k_fin: timedata row, stop rule
+  SLOT_MISC = 7
+};
+
+// ---- pointwise / reduction launchers (chs_pointwise.hip) -------------------
+int chs_launch_mu(Engine* E);                 // dU -> dMU, partials
+int chs_launch_pre(Engine* E);                // partials -> state (L2, delt, time)
+int chs_launch_spectral(Engine* E, const void* hmu);  // dHat <- (dHat + Seig*hmu)/CHeig (natural order)
+int chs_launch_sum(Engine* E, int ignore_halt);  // meanU <- mean(dU)
+int chs_launch_diag(Engine* E, int ignore_halt);  // dU -> diag partials
+int chs_launch_fin(Engine* E, int prepare_mode);
+int chs_launch_jitter(Engine* E);
+int chs_pointwise_alloc(Engine* E);
+void chs_pointwise_free(Engine* E);
+
+// ---- direct engine (chs_direct.hip) ----------------------------------------
+int chs_direct_init(Engine* E);
+void chs_direct_free(Engine* E);
+int chs_direct_dct2d(Engine* E, const void* in, void* out, void* tmp, bool inverse);
+
+// ---- fast engine (chs_fast.hip) ---------------------------------------------
+bool chs_fast_supported(int N, int dtype);
+int chs_fast_init(Engine* E);
+void chs_fast_free(Engine* E);
+int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse);  // natural in/out (tests)
+int chs_fast_enter(Engine* E);   // hat_U <- dctn(U) in engine-native order (solver.py:159)
+int chs_fast_step(Engine* E);    // K1..K3 of one timestep (between k_pre and k_diag hooks)

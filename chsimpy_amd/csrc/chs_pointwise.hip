@@ -1,0 +1,425 @@
+// chs_pointwise.hip -- pointwise sweeps, reductions and the device-side
+// bookkeeping kernels (time step control, timedata rows, stop rule).
+//
+// Reference lines implemented here:
+//   k_mu        chsimpy/solver.py:166-175 (+ the operands of 183 and 225)
+//   k_colmin    chsimpy/solver.py:183  (np.linalg.norm(.., ord=-1) = min column abs-sum)
+//   k_pre       chsimpy/solver.py:177-199,225
+//   k_spectral  chsimpy/solver.py:201-206 with chsimpy/utils.py:39-49
+//   k_diag      chsimpy/solver.py:213-228 (= 100-116 for prepare)
+//   k_fin       chsimpy/solver.py:118-134,230-249 ; chsimpy/timedata.py:8-10,51-63
+#include "chs_common.h"
+#include "chs_math.h"
+
+#define PW_THREADS 256
+#define PW_BAND 8  // rows per block in the banded sweeps
+
+// ---------------------------------------------------------------------------
+// k_mu: MU = EnergieEut(U); per-band sum(mu^2); per-band column sums of the
+// adaptive-step integrand (only when `want_col`).
+// grid.x = ceil(N/PW_BAND) row bands, threads sweep the columns.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void k_mu(const T* __restrict__ U, T* __restrict__ MU, DevConsts dc,
+                                                   const DevState* __restrict__ st, double* __restrict__ partMu,
+                                                   double* __restrict__ partCol, int force_col) {
+  __shared__ double scratch[32];
+  if (st->halt) return;
+  const int N = dc.N;
+  const int r0 = blockIdx.x * PW_BAND;
+  const int r1 = min(r0 + PW_BAND, N);
+  const bool want_col =
+      force_col || (dc.adaptive_time && st->computed_steps > 500 && (st->computed_steps % 2) == 0);
+  const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
+  double s2 = 0.0;
+  for (int c = threadIdx.x; c < N; c += PW_THREADS) {
+    double cs = 0.0;
+    for (int r = r0; r < r1; ++r) {
+      const T u = U[(size_t)r * N + c];
+      const T m = chs_mu<T>(u, RT, BRT, A0, A1);
+      MU[(size_t)r * N + c] = m;
+      const double md = (double)m;
+      s2 += md * md;
+      if (want_col) cs += chs_dt_integrand(md, dc.delt_max);
+    }
+    if (want_col) partCol[(size_t)blockIdx.x * N + c] = cs;
+  }
+  const double tot = block_sum(s2, scratch);
+  if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// k_colmin: column sums over the row bands, then the minimum over the block's
+// columns.  grid.x = ceil(N/PW_THREADS).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void k_colmin(const double* __restrict__ partCol, int nBands, int N,
+                                                       const DevState* __restrict__ st, int adaptive,
+                                                       double* __restrict__ partColMin) {
+  __shared__ double scratch[32];
+  if (st->halt) return;
+  if (!(adaptive && st->computed_steps > 500 && (st->computed_steps % 2) == 0)) return;
+  const int c = blockIdx.x * PW_THREADS + threadIdx.x;
+  double s = 1.0e300;
+  if (c < N) {
+    s = 0.0;
+    for (int b = 0; b < nBands; ++b) s += partCol[(size_t)b * N + c];
+  }
+  const double m = block_min(s, scratch);
+  if (threadIdx.x == 0) partColMin[blockIdx.x] = m;
+}
+
+// ---------------------------------------------------------------------------
+// k_pre (one block): L2 of the running step, adaptive time step, time
+// bookkeeping and the time-limit stop.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void k_pre(DevConsts dc, DevState* __restrict__ st,
+                                                    const double* __restrict__ partMu, int nPartMu,
+                                                    const double* __restrict__ partColMin, int nColMin) {
+  __shared__ double scratch[32];
+  if (st->halt) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nPartMu; i += PW_THREADS) s += partMu[i];
+  const double musq = block_sum(s, scratch);
+  double m = 1.0e300;
+  const bool adapt = dc.adaptive_time && st->computed_steps > 500 && (st->computed_steps % 2) == 0;
+  if (adapt) {
+    for (int i = threadIdx.x; i < nColMin; i += PW_THREADS) m = fmin(m, partColMin[i]);
+  }
+  const double delt_dyn = block_min(m, scratch);
+  if (threadIdx.x == 0) {
+#pragma clang fp contract(off)
+    const double N2 = (double)dc.N * (double)dc.N;
+    st->L2_cur = sqrt(musq) / N2;  // solver.py:225
+    double delt = st->delt;
+    if (adapt) {  // solver.py:184-188
+      const double delt_new = fmax(dc.delt0, delt_dyn);
+      if (delt_new / delt > 1.15)
+        delt = 0.75 * delt + 0.25 * delt_new;
+      else
+        delt = delt_new;
+      st->delt = delt;
+    }
+    // utils.py:41-42
+    const double lam1 = delt / dc.delx2;
+    st->lam1 = lam1;
+    st->lam2 = dc.kappa_tilde * lam1 / dc.delx2;
+    // solver.py:195-199
+    const double tds = st->time_delta_sum + delt;
+    st->time_delta_sum = tds;
+    const double tp = tds / dc.M_tilde;
+    st->time_passed = tp;
+    if (dc.time_limit_s > 0.0 && tp > dc.time_limit_s) {
+      st->stop_reason = CHS_STOP_TIME_LIMIT;
+      st->halt = 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_spectral (direct engine, natural order): hat_U <- (hat_U + Seig*hat_mu)/CHeig
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void k_spectral(T* __restrict__ hatU, const T* __restrict__ hatMu,
+                                                         const double* __restrict__ lam, int N,
+                                                         DevState* __restrict__ st) {
+  if (st->halt) return;
+  const double lam1 = st->lam1, lam2 = st->lam2;
+  const size_t total = (size_t)N * N;
+  for (size_t idx = (size_t)blockIdx.x * PW_THREADS + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * PW_THREADS) {
+    const int i = (int)(idx / N), j = (int)(idx - (size_t)i * N);
+    const T h = chs_spectral<T>(hatU[idx], hatMu[idx], lam[i], lam[j], lam1, lam2);
+    hatU[idx] = h;
+    if (idx == 0) st->meanU = (double)h / (double)N;  // ortho DCT-II DC term = sum(U)/N
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_sum / k_sum_fin: meanU <- mean(U) (prepare, and after jitter).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void k_sum(const T* __restrict__ U, int N, const DevState* __restrict__ st,
+                                                    double* __restrict__ partSum, int ignore_halt) {
+  __shared__ double scratch[32];
+  if (!ignore_halt && st->halt) return;
+  const int r0 = blockIdx.x * PW_BAND, r1 = min(r0 + PW_BAND, N);
+  double s = 0.0;
+  for (int c = threadIdx.x; c < N; c += PW_THREADS)
+    for (int r = r0; r < r1; ++r) s += (double)U[(size_t)r * N + c];
+  const double tot = block_sum(s, scratch);
+  if (threadIdx.x == 0) partSum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PW_THREADS) void k_sum_fin(const double* __restrict__ partSum, int n, int N,
+                                                        DevState* __restrict__ st, int ignore_halt) {
+  __shared__ double scratch[32];
+  if (!ignore_halt && st->halt) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += PW_THREADS) s += partSum[i];
+  const double tot = block_sum(s, scratch);
+  if (threadIdx.x == 0) st->meanU = tot / ((double)N * (double)N);
+}
+
+// ---------------------------------------------------------------------------
+// k_diag: one sweep over U for E (bulk density), E2 (np.gradient stencil),
+// PS and SA.  grid.x = row bands; partDiag[block][4] = {sE, sG, sPS, cSA}.
+// np.gradient(U, delx, axis=[0,1], edge_order=1): interior (f[i+1]-f[i-1])/(2 dx),
+// edges (f[1]-f[0])/dx and (f[N-1]-f[N-2])/dx.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void k_diag(const T* __restrict__ U, DevConsts dc,
+                                                     const DevState* __restrict__ st,
+                                                     double* __restrict__ partDiag, int ignore_halt) {
+  __shared__ double scratch[32];
+  if (!ignore_halt && st->halt) return;
+  const int N = dc.N;
+  const int r0 = blockIdx.x * PW_BAND, r1 = min(r0 + PW_BAND, N);
+  const double mean = st->meanU;
+  const double inv2dx = 1.0 / (2.0 * dc.delx), invdx = 1.0 / dc.delx;
+  const T RT = (T)dc.RT, B = (T)dc.B, A0 = (T)dc.A0, A1 = (T)dc.A1;
+  double sE = 0.0, sG = 0.0, sPS = 0.0, cSA = 0.0;
+  for (int c = threadIdx.x; c < N; c += PW_THREADS) {
+    for (int r = r0; r < r1; ++r) {
+      const size_t o = (size_t)r * N + c;
+      const T u = U[o];
+      const double ud = (double)u;
+      double gx, gy;
+      if (r == 0)
+        gx = ((double)U[o + N] - ud) * invdx;
+      else if (r == N - 1)
+        gx = (ud - (double)U[o - N]) * invdx;
+      else
+        gx = ((double)U[o + N] - (double)U[o - N]) * inv2dx;
+      if (c == 0)
+        gy = ((double)U[o + 1] - ud) * invdx;
+      else if (c == N - 1)
+        gy = (ud - (double)U[o - 1]) * invdx;
+      else
+        gy = ((double)U[o + 1] - (double)U[o - 1]) * inv2dx;
+      sG += gx * gx + gy * gy;
+      sE += (double)chs_energy_density<T>(u, RT, B, A0, A1);
+      sPS += fabs(ud - mean);
+      cSA += (ud < dc.threshold) ? 1.0 : 0.0;
+    }
+  }
+  const double tE = block_sum(sE, scratch);
+  const double tG = block_sum(sG, scratch);
+  const double tP = block_sum(sPS, scratch);
+  const double tS = block_sum(cSA, scratch);
+  if (threadIdx.x == 0) {
+    double* p = partDiag + (size_t)blockIdx.x * 4;
+    p[0] = tE; p[1] = tG; p[2] = tP; p[3] = tS;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_fin (one block): reduce the sweep partials, Ra of row int(N/2)+1, write the
+// timedata row, advance the counters and apply the energy stop rule.
+// Row layout (timedata.py:9): [it, E, E2, SA, domtime, Ra, L2, PS, delt].
+// Slot 4 carries time_passed; the host applies ** (1/3) (solver.py:230) with
+// the same libm pow the reference's Python float uses.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void k_fin(const T* __restrict__ U, DevConsts dc, DevState* __restrict__ st,
+                                                    const double* __restrict__ partDiag, int nPart,
+                                                    double* __restrict__ rows, long long rowsCap, int prepare_mode) {
+  __shared__ double scratch[32];
+  if (!prepare_mode && st->halt) return;
+  const int N = dc.N;
+  double sE = 0.0, sG = 0.0, sP = 0.0, sS = 0.0;
+  for (int i = threadIdx.x; i < nPart; i += PW_THREADS) {
+    sE += partDiag[(size_t)i * 4 + 0];
+    sG += partDiag[(size_t)i * 4 + 1];
+    sP += partDiag[(size_t)i * 4 + 2];
+    sS += partDiag[(size_t)i * 4 + 3];
+  }
+  sE = block_sum(sE, scratch);
+  sG = block_sum(sG, scratch);
+  sP = block_sum(sP, scratch);
+  sS = block_sum(sS, scratch);
+  // Ra: solver.py:226-227 (row int(N/2)+1; two passes over one row)
+  const int rr = N / 2 + 1;
+  double s = 0.0;
+  if (rr < N)
+    for (int c = threadIdx.x; c < N; c += PW_THREADS) s += (double)U[(size_t)rr * N + c];
+  const double rmean = block_sum(s, scratch) / (double)N;
+  s = 0.0;
+  if (rr < N)
+    for (int c = threadIdx.x; c < N; c += PW_THREADS) s += fabs((double)U[(size_t)rr * N + c] - rmean);
+  const double Ra = block_sum(s, scratch) / (double)N;
+
+  if (threadIdx.x == 0) {
+#pragma clang fp contract(off)
+    const double N2 = (double)N * (double)N;
+    const double L2sq = dc.L * dc.L;
+    const double E2 = 0.5 * dc.Amr * dc.kappa_tilde * L2sq * (sG / N2);
+    const double E = dc.Amr * L2sq * (sE / N2) + E2;
+    const double PS = sP / N2;
+    if (prepare_mode) {
+      double* row = rows;  // row 0 of the prepare buffer
+      row[0] = 0.0; row[1] = E; row[2] = E2; row[3] = 0.0; row[4] = 0.0;
+      row[5] = Ra; row[6] = 0.0; row[7] = PS; row[8] = st->delt;
+      st->E2_0 = E2;
+      st->E2_prev = E2;
+      st->tau0 = 0.0; st->t0 = 0.0;
+      st->stop_reason = CHS_STOP_NONE;
+      st->computed_steps = 1;
+      st->halt = 0;
+      st->nan_flag = (E != E || E2 != E2 || Ra != Ra || PS != PS) ? 1 : 0;
+      st->rows_written = 0;
+    } else {
+      const long long k = st->rows_written;
+      const double SA = sS / N2;
+      if (k < rowsCap) {
+        double* row = rows + k * 9;
+        row[0] = (double)st->computed_steps; row[1] = E; row[2] = E2; row[3] = SA;
+        row[4] = st->time_passed; row[5] = Ra; row[6] = st->L2_cur; row[7] = PS; row[8] = st->delt;
+      }
+      st->rows_written = k + 1;
+      const double L2v = st->L2_cur, tp = st->time_passed;
+      if (E != E || E2 != E2 || Ra != Ra || PS != PS || L2v != L2v || tp != tp || SA != SA) {
+        st->nan_flag = 1;  // timedata.py:10 fires before computed_steps += 1
+        st->halt = 1;
+      } else {
+        const long long cs = st->computed_steps + 1;  // solver.py:240
+        st->computed_steps = cs;
+        // solver.py:242-249 ; timedata.py:63
+        if (!st->skip_check && st->E2_prev > E2 && E2 > st->E2_0) {
+          st->tau0 = (double)cs;
+          st->t0 = st->time_passed;
+          if (!dc.full_sim) {
+            st->stop_reason = CHS_STOP_ENERGY;
+            st->halt = 1;
+          } else {
+            st->skip_check = 1;
+          }
+        }
+        st->E2_prev = E2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_jitter: U += jitter*(2*noise-1)   (solver.py:210-211)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void k_jitter(T* __restrict__ U, const T* __restrict__ noise, double jitter,
+                                                       size_t total, const DevState* __restrict__ st) {
+  if (st->halt) return;
+  for (size_t i = (size_t)blockIdx.x * PW_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * PW_THREADS) {
+#pragma clang fp contract(off)
+    U[i] = (T)((double)U[i] + jitter * (2.0 * (double)noise[i] - 1.0));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+int chs_pointwise_alloc(Engine* E) {
+  const int N = E->N;
+  E->nBands = (N + PW_BAND - 1) / PW_BAND;
+  E->nDiagBlocks = E->nBands;
+  E->nColMinBlocks = (N + PW_THREADS - 1) / PW_THREADS;
+  CHS_HIP(hipMalloc(&E->dPartMu, sizeof(double) * (size_t)E->nBands));
+  CHS_HIP(hipMalloc(&E->dPartDiag, sizeof(double) * 4 * (size_t)E->nDiagBlocks));
+  CHS_HIP(hipMalloc(&E->dPartSum, sizeof(double) * (size_t)E->nBands));
+  CHS_HIP(hipMalloc(&E->dPartColMin, sizeof(double) * (size_t)E->nColMinBlocks));
+  CHS_HIP(hipMalloc(&E->dPartCol, sizeof(double) * (size_t)E->nBands * N));
+  return CHS_OK;
+}
+void chs_pointwise_free(Engine* E) {
+  hipFree(E->dPartMu); hipFree(E->dPartDiag); hipFree(E->dPartSum);
+  hipFree(E->dPartColMin); hipFree(E->dPartCol);
+}
+
+#define DISPATCH_T(E, expr_d, expr_f) \
+  do { if ((E)->dtype == CHS_F64) { expr_d; } else { expr_f; } } while (0)
+
+int chs_launch_mu(Engine* E) {
+  chs_slot_begin(E, SLOT_MU);
+  DISPATCH_T(E,
+    (k_mu<double><<<E->nBands, PW_THREADS, 0, E->stream>>>((const double*)E->dU, (double*)E->dMU, E->dc, E->dState,
+                                                            E->dPartMu, E->dPartCol, 0)),
+    (k_mu<float><<<E->nBands, PW_THREADS, 0, E->stream>>>((const float*)E->dU, (float*)E->dMU, E->dc, E->dState,
+                                                           E->dPartMu, E->dPartCol, 0)));
+  chs_slot_end(E, SLOT_MU);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
+int chs_launch_pre(Engine* E) {
+  chs_slot_begin(E, SLOT_PRE);
+  if (E->dc.adaptive_time)
+    k_colmin<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dPartCol, E->nBands, E->N, E->dState,
+                                                              E->dc.adaptive_time, E->dPartColMin);
+  k_pre<<<1, PW_THREADS, 0, E->stream>>>(E->dc, E->dState, E->dPartMu, E->nBands, E->dPartColMin,
+                                         E->nColMinBlocks);
+  chs_slot_end(E, SLOT_PRE);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
+int chs_launch_spectral(Engine* E, const void* hmu) {
+  const size_t total = (size_t)E->N * E->N;
+  int blocks = (int)((total + PW_THREADS - 1) / PW_THREADS);
+  if (blocks > 4096) blocks = 4096;
+  chs_slot_begin(E, SLOT_SPEC);
+  DISPATCH_T(E,
+    (k_spectral<double><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dHat, (const double*)hmu, E->dLambda, E->N,
+                                                               E->dState)),
+    (k_spectral<float><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dHat, (const float*)hmu, E->dLambda, E->N,
+                                                              E->dState)));
+  chs_slot_end(E, SLOT_SPEC);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
+int chs_launch_sum(Engine* E, int ignore_halt) {
+  chs_slot_begin(E, SLOT_MISC);
+  DISPATCH_T(E,
+    (k_sum<double><<<E->nBands, PW_THREADS, 0, E->stream>>>((const double*)E->dU, E->N, E->dState, E->dPartSum, ignore_halt)),
+    (k_sum<float><<<E->nBands, PW_THREADS, 0, E->stream>>>((const float*)E->dU, E->N, E->dState, E->dPartSum, ignore_halt)));
+  k_sum_fin<<<1, PW_THREADS, 0, E->stream>>>(E->dPartSum, E->nBands, E->N, E->dState, ignore_halt);
+  chs_slot_end(E, SLOT_MISC);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
+int chs_launch_diag(Engine* E, int ignore_halt) {
+  chs_slot_begin(E, SLOT_DIAG);
+  DISPATCH_T(E,
+    (k_diag<double><<<E->nDiagBlocks, PW_THREADS, 0, E->stream>>>((const double*)E->dU, E->dc, E->dState,
+                                                                   E->dPartDiag, ignore_halt)),
+    (k_diag<float><<<E->nDiagBlocks, PW_THREADS, 0, E->stream>>>((const float*)E->dU, E->dc, E->dState,
+                                                                  E->dPartDiag, ignore_halt)));
+  chs_slot_end(E, SLOT_DIAG);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
+int chs_launch_fin(Engine* E, int prepare_mode) {
+  chs_slot_begin(E, SLOT_FIN);
+  DISPATCH_T(E,
+    (k_fin<double><<<1, PW_THREADS, 0, E->stream>>>((const double*)E->dU, E->dc, E->dState, E->dPartDiag,
+                                                     E->nDiagBlocks, E->dRows, E->rowsCap, prepare_mode)),
+    (k_fin<float><<<1, PW_THREADS, 0, E->stream>>>((const float*)E->dU, E->dc, E->dState, E->dPartDiag,
+                                                    E->nDiagBlocks, E->dRows, E->rowsCap, prepare_mode)));
+  chs_slot_end(E, SLOT_FIN);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
+int chs_launch_jitter(Engine* E) {
+  const size_t total = (size_t)E->N * E->N;
+  int blocks = (int)((total + PW_THREADS - 1) / PW_THREADS);
+  if (blocks > 4096) blocks = 4096;
+  chs_slot_begin(E, SLOT_MISC);
+  DISPATCH_T(E,
+    (k_jitter<double><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, (const double*)E->dNoise, E->jitter, total,
+                                                             E->dState)),
+    (k_jitter<float><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, (const float*)E->dNoise, E->jitter, total,
+                                                            E->dState)));
+  chs_slot_end(E, SLOT_MISC);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}

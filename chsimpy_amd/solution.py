@@ -1,0 +1,69 @@
+"""Derived constants and results of one run: ``chsimpy/solution.py:17-67``."""
+import numpy as np
+
+from . import utils
+from .timedata import TimeData
+
+_TIMEDATA_NAMES = ('E', 'E2', 'SA', 'domtime', 'Ra', 'L2', 'PS', 'delt', 'it_range')
+
+
+class Solution:
+    def __init__(self, params=None):
+        p = self.params = params
+        self.U = None
+        self.timedata = None
+        # molar area [um^2/mol], solution.py:25
+        self.Am = (25.13 * 1e6 / p.N_A) ** (2 / 3) * p.N_A
+        # discretisation, solution.py:28-29
+        self.delx = p.L / (p.N - 1)
+        self.delx2 = self.delx ** 2
+        # solution.py:31-37
+        self.RT = p.R * p.temp
+        self.BRT = p.B * p.R * p.temp
+        self.Amr = 1 / self.Am
+        self.A0 = p.func_A0(p.temp)
+        self.A1 = p.func_A1(p.temp)
+        self.time_fac = (1 / p.M_tilde) * p.delt
+        self.M = p.M_tilde / self.Am
+        # gradient-energy parameter, solution.py:39-50
+        if p.kappa_tilde is None:
+            self.kappa_base = utils.get_distance_common_tangent(
+                R=p.R, T=p.temp, B=p.B, A0=self.A0, A1=self.A1, at=p.XXX)
+            self.kappa_tilde = self.kappa_base / (0.1602564 * 64) ** 2
+        else:
+            self.kappa_tilde = p.kappa_tilde
+        self.kappa = self.kappa_tilde * self.Amr
+        # the device engine keeps only this 1-D table (CHeig/Seig are formed on the fly)
+        self.lam = utils.eigenvalues_1d(p.N)
+        self.restime = 0
+        self.tau0 = 0
+        self.t0 = 0
+        self.computed_steps = 0
+        self.stop_reason = 'None'
+
+    # The N x N grids of solution.py:52-55, on demand (host convenience only).
+    @property
+    def CHeig(self):
+        return utils.get_coefficients(self.params.N, self.kappa_tilde, self.params.delt, self.delx2)[0]
+
+    @property
+    def Seig(self):
+        return utils.get_coefficients(self.params.N, self.kappa_tilde, self.params.delt, self.delx2)[1]
+
+    def __getattr__(self, name):
+        # timedata column proxy, solution.py:63-67
+        if name in _TIMEDATA_NAMES:
+            td = self.__dict__.get('timedata')
+            if td is not None and hasattr(td, name):
+                return getattr(td, name)
+        raise AttributeError("No such attribute: " + name)
+
+    def scalars(self):
+        out = {}
+        for k, v in self.__dict__.items():
+            if k.startswith('_') or k in ('params', 'U', 'timedata', 'lam'):
+                continue
+            if isinstance(v, (np.floating,)):
+                v = float(v)
+            out[k] = v
+        return out

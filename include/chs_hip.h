@@ -1,0 +1,164 @@
+/* chs_hip.h -- C ABI of the MI355X (gfx950) Cahn-Hilliard timestep engine.
+ *
+ * Drop-in boundary for ONE hot path of uncertaintyhub/chsimpy: the per-timestep
+ * solver loop.  The reference has no FFI of its own; the seam is the Python
+ * method pair
+ *     Solver.prepare()                 chsimpy/solver.py:84-135
+ *     Solver.solve_or_resume(nsteps)   chsimpy/solver.py:137-252
+ * (called from chsimpy/simulator.py:41,43,69 and examples/benchmark.py:72-74).
+ * A ctypes-backed `Solver` look-alike (chsimpy_amd/solver.py) binds exactly the
+ * entry points below; INTEGRATION.md shows the stub a chsimpy maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every host buffer, the
+ *     library owns the device buffers for the lifetime of the handle;
+ *   - one opaque handle per simulation, one HIP stream per handle, no global
+ *     state besides the thread-local last-error string -> 8 handles can live on
+ *     8 devices of a node (ensemble runs, chsimpy/experiment.py:84-126);
+ *   - every call is synchronous on return;
+ *   - return value: CHS_OK (0) or a negative CHS_E* code; chs_last_error()
+ *     gives the text.
+ */
+#ifndef CHS_HIP_H
+#define CHS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHS_OK 0
+#define CHS_EINVAL (-1)   /* bad argument / unsupported configuration            */
+#define CHS_EHIP (-2)     /* a HIP runtime call failed                           */
+#define CHS_ENAN (-3)     /* a recorded scalar became NaN (chsimpy/timedata.py:10) */
+#define CHS_ESTATE (-4)   /* call order violated (e.g. step before prepare:
+                             the assert at chsimpy/solver.py:139)                */
+
+/* arithmetic type of the device path */
+#define CHS_F64 0
+#define CHS_F32 1
+
+/* transform engine */
+#define CHS_ENGINE_AUTO 0   /* fast for N = power of two >= 128, else direct     */
+#define CHS_ENGINE_DIRECT 1 /* dense cosine-matrix products, any N >= 8          */
+#define CHS_ENGINE_FAST 2   /* LDS-staged FFT-based row/column DCT passes        */
+
+/* stop reasons (chsimpy/solver.py:133,198,246) */
+#define CHS_STOP_NONE 0
+#define CHS_STOP_ENERGY 1
+#define CHS_STOP_TIME_LIMIT 2
+
+/* Scalars the loop reads.  They are what chsimpy/solution.py:25-55 derives from
+ * chsimpy/parameters.py:24-61; the host wrapper computes them exactly as the
+ * reference does and hands them over. */
+typedef struct chs_consts {
+  int32_t N;              /* grid is N x N                       parameters.py:25 */
+  int32_t dtype;          /* CHS_F64 | CHS_F32                                    */
+  int32_t device;         /* HIP device ordinal                                   */
+  int32_t engine;         /* CHS_ENGINE_*                                         */
+  int32_t adaptive_time;  /* parameters.py:57 ; solver.py:177-193                 */
+  int32_t full_sim;       /* parameters.py:50 ; solver.py:245-249                 */
+  double RT;              /* R*temp                              solution.py:31   */
+  double BRT;             /* B*R*temp                            solution.py:32   */
+  double B;               /*                                     parameters.py:31 */
+  double A0, A1;          /* func_A0(temp), func_A1(temp)        solution.py:34-35 */
+  double Amr;             /* 1/Am                                solution.py:33   */
+  double kappa_tilde;     /*                                     solution.py:39-48 */
+  double L;               /*                                     parameters.py:26 */
+  double delx;            /* L/(N-1)                             solution.py:28   */
+  double delt;            /* initial time step                   parameters.py:36 */
+  double delt_max;        /*                                     parameters.py:37 */
+  double M_tilde;         /*                                     parameters.py:38 */
+  double threshold;       /*                                     parameters.py:41 */
+  double time_limit_s;    /* time_max*60, <= 0: none             solver.py:151-153 */
+} chs_consts;
+
+/* Solver-side state that survives between solve_or_resume calls
+ * (chsimpy/solver.py:50-54) plus the Solution counters (solution.py:57-61). */
+typedef struct chs_state {
+  double delt;            /* solver.py:54, updated by 185-188   */
+  double time_delta_sum;  /* solver.py:51,195                   */
+  double time_passed;     /* solver.py:52,196                   */
+  double tau0;            /* solution.py:58 ; solver.py:243     */
+  double t0;              /* solution.py:59 ; solver.py:244     */
+  int64_t computed_steps; /* solution.py:60 ; solver.py:134,240 */
+  int32_t skip_check;     /* solver.py:50,249                   */
+  int32_t stop_reason;    /* CHS_STOP_*                         */
+} chs_state;
+
+typedef struct chs_handle_s* chs_handle;
+
+/* Create an engine for one simulation.  `lambda` is the host-computed 1-D table
+ * lam_i = 2cos(pi i/(N-1)) - 2, i = 0..N-1 (chsimpy/utils.py:34-36); the N x N
+ * grids CHeig/Seig of utils.py:39-49 are never materialised, they are formed on
+ * the fly from this table and the current delt. */
+int chs_create(const chs_consts* consts, const double* lambda, chs_handle* out);
+int chs_destroy(chs_handle h);
+
+/* Upload the N x N row-major float64 field (the reference's U_init / solution.U).
+ * Replaces `U = self.U_init.copy()` (solver.py:85) and `U = self.solution.U`
+ * (solver.py:158). */
+int chs_set_U(chs_handle h, const double* host_U);
+/* Download the current field (solver.py:251 `self.solution.U = U`). */
+int chs_get_U(chs_handle h, double* host_U);
+
+/* Step-0 diagnostics of solver.py:100-127 on the current field.  Fills
+ * row0 = [it=0, E, E2, SA=0, domtime=0, Ra, L2=0, PS, delt] (column order of
+ * chsimpy/timedata.py:9) and resets computed_steps=1, tau0=t0=0,
+ * stop_reason=None (solver.py:128-135).  delt / time_delta_sum / skip_check
+ * are NOT reset, exactly as in the reference. */
+int chs_prepare(chs_handle h, double row0[9]);
+
+/* Run up to `nsteps` iterations of solver.py:165-249 on the device without any
+ * per-step host synchronisation.  On entry hat_U = dctn(U) is re-derived
+ * (solver.py:159).  The caller passes the iteration count of
+ * range(itbegin, nsteps) (solver.py:160-165).  `rows` receives one 9-column
+ * timedata row per completed step ([nsteps][9], column order timedata.py:9);
+ * `*steps_done` how many were completed (fewer than nsteps after an energy or
+ * time-limit stop, which are decided on the device, solver.py:197-199,242-249).
+ * Returns CHS_ENAN when a recorded scalar is NaN (timedata.py:10); the rows up
+ * to and including the NaN row are still returned. */
+int chs_step_n(chs_handle h, int64_t nsteps, int32_t flags, double* rows, int64_t* steps_done);
+/* flags for chs_step_n */
+#define CHS_STEP_CARRY_HAT 1 /* do not re-derive hat_U on entry: continue the loop of the
+                                previous call (used to feed per-step host jitter noise while
+                                keeping the reference's carried hat_U, solver.py:206-211) */
+
+int chs_get_state(chs_handle h, chs_state* out);
+int chs_set_state(chs_handle h, const chs_state* in);
+
+/* U += jitter * (2*noise - 1) with host-supplied noise (solver.py:210-211).  The
+ * reference draws `noise` from its seeded host generator; keeping the draw on the
+ * host keeps its stream bit-identical.  hat_U is left untouched, as in the
+ * reference. */
+int chs_set_jitter_noise(chs_handle h, double jitter, const double* host_noise);
+
+/* Test / diagnostic hooks (not on the reference seam). */
+/* 2-D orthonormal DCT-II (inverse=0) or DCT-III (inverse=1) of a host array
+ * through the handle's transform engine: scipy.fftpack.dctn/idctn(norm='ortho')
+ * as called at solver.py:159,201,208. */
+int chs_dctn(chs_handle h, const double* host_in, double* host_out, int inverse);
+/* EnergieEut of solver.py:166-175 for the current field. */
+int chs_get_mu(chs_handle h, double* host_mu);
+/* Which engine the handle resolved to (CHS_ENGINE_DIRECT / CHS_ENGINE_FAST). */
+int chs_engine(chs_handle h);
+
+/* Measurement hooks used by bench.py. */
+#define CHS_NKERNELS 8
+/* Names of the per-step kernels of the resolved engine, slot i (NULL beyond). */
+const char* chs_kernel_name(chs_handle h, int slot);
+/* Run `nsteps` steps with HIP events bracketing every kernel launch on the
+ * handle's stream; ms[i] receives the summed device time of slot i, calls[i]
+ * its launch count.  Results are identical to chs_step_n. */
+int chs_profile_steps(chs_handle h, int64_t nsteps, double ms[CHS_NKERNELS], int64_t calls[CHS_NKERNELS]);
+/* Device time (ms, HIP events on the handle's stream) of the last chs_step_n. */
+double chs_last_step_ms(chs_handle h);
+
+const char* chs_last_error(void);
+const char* chs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHS_HIP_H */

@@ -1,0 +1,234 @@
+"""GPU parity tests (``-m gpu``): the HIP path, called through the C ABI, against the
+oracle on identical inputs.  Tolerance: BASELINE.json's north_star asks for per-step
+U within rtol 1e-9 of the numpy/scipy path (fp64); energies E/E2 likewise.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.fftpack as scifft
+
+import chsimpy_amd
+from chsimpy_amd import _lib
+from oracle import chs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KAPPA = 0.0002989112919661156
+RTOL = 1e-9
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def make(N, ntmax, engine='auto', **kw):
+    p = chsimpy_amd.Parameters()
+    p.N, p.ntmax, p.full_sim, p.kappa_tilde, p.engine = N, ntmax, True, KAPPA, engine
+    for k, v in kw.items():
+        setattr(p, k, v)
+    if 'threshold' not in kw:
+        p.threshold = p.XXX
+    return p
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def compare_run(p, okw, U_init=None, rtol=RTOL, cols=(1, 2, 3, 4, 5, 6, 7, 8)):
+    s = chsimpy_amd.Solver(p, U_init)
+    s.prepare()
+    sol = s.solve_or_resume()
+    o = orc.OracleSolver(orc.make_params(p.N, p.ntmax, **okw), U_init)
+    o.prepare()
+    o.solve_or_resume()
+    td, to = sol.timedata.data(), o.timedata.data()
+    assert td.shape == to.shape
+    assert np.array_equal(td[:, 0], to[:, 0])
+    for c in cols:
+        assert np.allclose(td[:, c], to[:, c], rtol=rtol, atol=1e-300), (c, relerr(td[:, c], to[:, c]))
+    assert np.allclose(sol.U, o.U, rtol=rtol, atol=0), relerr(sol.U, o.U)
+    assert sol.computed_steps == o.computed_steps
+    assert sol.stop_reason == o.stop_reason
+    assert sol.tau0 == o.tau0 and sol.t0 == pytest.approx(o.t0, rel=1e-12)
+    assert s.time_passed == pytest.approx(o.time_passed, rel=1e-12)
+    s.close()
+    return sol, o
+
+
+@pytest.mark.parametrize("engine,N", [('direct', 64), ('direct', 100), ('direct', 128), ('fast', 128), ('fast', 256)])
+def test_dctn_matches_scipy(gpu, engine, N):
+    p = make(N, 2, engine)
+    s = chsimpy_amd.Solver(p)
+    eng = s._get_engine()
+    assert eng.engine == engine
+    X = np.random.default_rng(N).standard_normal((N, N))
+    Y = eng.dctn(X)
+    Yr = scifft.dctn(X, norm='ortho')
+    assert np.max(np.abs(Y - Yr)) < 1e-12 * np.max(np.abs(Yr))
+    Z = eng.dctn(Yr, inverse=True)
+    assert np.max(np.abs(Z - X)) < 1e-12 * np.max(np.abs(X))
+    s.close()
+
+
+@pytest.mark.parametrize("engine", ['direct', 'fast'])
+def test_mu_pointwise(gpu, engine):
+    p = make(128, 2, engine)
+    s = chsimpy_amd.Solver(p)
+    eng = s._get_engine()
+    eng.set_U(s.U_init)
+    o = orc.OracleSolver(orc.make_params(128, 2))
+    assert np.allclose(eng.get_mu(), o.mu(o.U_init), rtol=1e-13, atol=0)
+    s.close()
+
+
+@pytest.mark.parametrize("engine", ['direct', 'fast'])
+def test_config0_n128_200steps_vs_oracle_and_golden(gpu, engine):
+    """BASELINE.json configs[0]: N=128, ntmax=200, seed=2023, cinit=0.875."""
+    sol, o = compare_run(make(128, 200, engine), {})
+    g = np.load(os.path.join(GOLD, 'n128_seed2023_200steps.npz'))
+    assert np.allclose(sol.timedata.data()[:, 1:3], g['timedata'][:, 1:3], rtol=RTOL, atol=0)
+    assert np.allclose(sol.U, g['U_final'], rtol=RTOL, atol=0)
+    # reference observations
+    assert sol.E[-1] == pytest.approx(-5.453709377934683e-11, rel=1e-9)
+    assert sol.E2[-1] == pytest.approx(8.73563379288026e-18, rel=1e-9)
+
+
+@pytest.mark.parametrize("engine", ['direct', 'fast'])
+def test_golden_lcg_fixture(gpu, engine):
+    g = np.load(os.path.join(GOLD, 'n64_lcg_40steps.npz'))
+    if engine == 'fast':
+        pytest.skip("fast engine starts at N=128")
+    p = make(64, 40, engine, generator='lcg')
+    s = chsimpy_amd.Solver(p)
+    assert np.array_equal(s.U_init, g['U_init'])
+    s.prepare()
+    sol = s.solve_or_resume()
+    assert np.allclose(sol.timedata.data(), g['timedata'], rtol=RTOL, atol=1e-300)
+    assert np.allclose(sol.U, g['U_final'], rtol=RTOL, atol=0)
+    s.close()
+
+
+def test_non_power_of_two_n100(gpu):
+    """`benchmark.py -N 100` of the reference's smoke script (tests/run-tests.sh:15)."""
+    compare_run(make(100, 60, 'auto'), {})
+
+
+def test_config1_n512_1000steps(gpu):
+    """BASELINE.json configs[1]: N=512, ntmax=1000, fp64 -- U/E/E2 vs numpy at rtol 1e-9."""
+    compare_run(make(512, 1000, 'auto'), {})
+
+
+def test_resume_chunks_match_oracle_chunks(gpu):
+    """solve_or_resume in chunks (simulator.py:62-81): nsteps-1 on the first call,
+    hat_U re-derived per call."""
+    p = make(128, 0)
+    s = chsimpy_amd.Solver(p)
+    o = orc.OracleSolver(orc.make_params(128, 0))
+    s.prepare(); o.prepare()
+    for chunk in (5, 7, 1, 12):
+        sol = s.solve_or_resume(chunk)
+        o.solve_or_resume(chunk)
+        assert sol.computed_steps == o.computed_steps
+        assert np.allclose(sol.U, o.U, rtol=RTOL, atol=0)
+    assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=RTOL, atol=1e-300)
+    # prepare() again resets the record but not delt/time_delta_sum (as the reference)
+    s.prepare(); o.prepare()
+    sol = s.solve_or_resume(4); o.solve_or_resume(4)
+    assert sol.timedata.data().shape == (4, 9)
+    assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=RTOL, atol=1e-300)
+    s.close()
+
+
+def test_energy_stop_without_full_sim(gpu):
+    """full_sim=False: stop at the first step with E2[it-1] > E2[it] > E2[0]; the
+    returned U is the one of the stopping step (solver.py:242-251).  delt=3e-6 reaches
+    the E2 peak after 71 steps on the default N=64 start field."""
+    p = make(64, 6000, 'auto', full_sim=False, delt=3e-6)
+    sol, o = compare_run(p, dict(full_sim=False, delt=3e-6), rtol=1e-8)
+    assert sol.stop_reason == 'energy' and sol.computed_steps == 72 and sol.tau0 == 72
+    # with full_sim the same run continues and only records tau0/t0 once
+    p = make(64, 100, 'auto', full_sim=True, delt=3e-6)
+    sol, o = compare_run(p, dict(full_sim=True, delt=3e-6), rtol=1e-7)
+    assert sol.stop_reason == 'None' and sol.computed_steps == 100 and sol.tau0 == 72
+
+
+def test_time_limit_stop(gpu):
+    p = make(64, 500, 'auto', time_max=30 * 3e-8 / 1.71e-8 / 60)  # ~30 steps of simulated time
+    sol, o = compare_run(p, dict(time_max=p.time_max))
+    assert sol.stop_reason == 'time-limit' and sol.computed_steps < 40
+
+
+def test_adaptive_time(gpu):
+    """adaptive_time beyond step 500 (solver.py:177-193) against the golden delt history."""
+    g = np.load(os.path.join(GOLD, 'n64_adaptive_600.npz'))
+    assert len(np.unique(g['timedata'][:, 8])) > 3  # the step really adapts
+    p = make(64, 600, 'auto', adaptive_time=True)
+    s = chsimpy_amd.Solver(p)
+    s.prepare()
+    sol = s.solve_or_resume()
+    assert np.allclose(sol.timedata.data()[:, 8], g['timedata'][:, 8], rtol=1e-9, atol=0)
+    assert np.allclose(sol.timedata.data()[:, 1:3], g['timedata'][:, 1:3], rtol=1e-8, atol=0)
+    assert np.allclose(sol.U, g['U_final'], rtol=1e-8, atol=0)
+    s.close()
+
+
+def test_jitter_host_noise_stream(gpu):
+    p = make(64, 12, 'auto', jitter=0.001)
+    compare_run(p, dict(jitter=0.001))
+
+
+def test_nan_raises_assertion_like_the_reference(gpu):
+    N = 64
+    U0 = np.full((N, N), 0.875)
+    U0[3, 4] = 1.5  # outside (0,1): log of a negative number
+    p = make(N, 5)
+    s = chsimpy_amd.Solver(p, U0)
+    with pytest.raises(AssertionError):
+        s.prepare()
+        s.solve_or_resume()
+    s.close()
+
+
+def test_properties_at_full_size(gpu):
+    """Size-independent properties at BASELINE's headline size (N=4096): transform
+    round trip, mass conservation, fixed point, linearity of the transform."""
+    N = 4096
+    p = make(N, 4)
+    s = chsimpy_amd.Solver(p)
+    eng = s._get_engine()
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((N, N))
+    Y = eng.dctn(X)
+    assert Y[0, 0] == pytest.approx(X.sum() / N, rel=1e-10, abs=1e-9)
+    assert np.sum(Y * Y) == pytest.approx(np.sum(X * X), rel=1e-12)  # orthonormal: Parseval
+    Z = eng.dctn(Y, inverse=True)
+    assert np.max(np.abs(Z - X)) < 1e-11
+    # spot-check 3 columns of the transform against scipy along axis 0 then 1
+    T = scifft.dct(scifft.dct(X[:, :], axis=1, norm='ortho')[:, [0, 17, N - 1]], axis=0, norm='ortho')
+    assert np.max(np.abs(Y[:, [0, 17, N - 1]] - T)) < 1e-10
+    s.prepare()
+    sol = s.solve_or_resume(4)
+    assert sol.U.mean() == pytest.approx(s.U_init.mean(), rel=1e-13)
+    assert sol.timedata.data().shape == (4, 9)
+    s.close()
+    # fixed point
+    p = make(N, 3)
+    s = chsimpy_amd.Solver(p, np.full((N, N), 0.8))
+    s.prepare()
+    sol = s.solve_or_resume()
+    assert np.max(np.abs(sol.U - 0.8)) < 1e-13
+    assert np.all(np.abs(sol.E2) < 1e-40)
+    s.close()
+
+
+def test_simulator_export_csv(gpu, tmp_path):
+    p = make(64, 10)
+    p.export_csv = 'U,E,E2,SA'
+    p.file_id = str(tmp_path / 'run')
+    sim = chsimpy_amd.Simulator(p)
+    sol = sim.solve()
+    base = sim.export()
+    assert base == p.file_id + '.solution'
+    from chsimpy_amd import utils
+    assert np.array_equal(utils.csv_import_matrix(base + '.U.csv'), sol.U)
+    assert np.array_equal(utils.csv_import_matrix(base + '.E2.csv'), sol.E2)
+    assert utils.csv_import_matrix(base + '.E.csv').shape == (10,)
