@@ -131,6 +131,8 @@ struct Engine {
   double* dPartDiag = nullptr; // per-block [sE, sG, sPS, cSA]
   double* dPartSum = nullptr;  // per-block sum(U)
   int nBands = 0;              // row bands used by the pointwise kernels
+  int nPartMu = 0;             // number of sum(mu^2) partials the running engine produces
+  double* dPartMuAux = nullptr; // scratch partials of the column-sum-only sweep
   int nDiagBlocks = 0;
   int nColMinBlocks = 0;
 
@@ -167,6 +169,7 @@ enum {
 
 // ---- pointwise / reduction launchers (chs_pointwise.hip) -------------------
 int chs_launch_mu(Engine* E);                 // dU -> dMU, partials
+int chs_launch_mu_colsums(Engine* E);         // dU -> per-band column sums of the adaptive-step integrand only
 int chs_launch_pre(Engine* E);                // partials -> state (L2, delt, time)
 int chs_launch_spectral(Engine* E, const void* hmu);  // dHat <- (dHat + Seig*hmu)/CHeig (natural order)
 int chs_launch_sum(Engine* E, int ignore_halt);  // meanU <- mean(dU)

@@ -1,8 +1,495 @@
-// placeholder, replaced below
+// chs_fast.hip -- fast transform engine: three kernels per timestep.
+//
+//   k_row_fwd  reads U rows, evaluates EnergieEut (chsimpy/solver.py:166-175) on the fly,
+//              DCT-II along the row, writes T1                      [1 read + 1 write of N^2]
+//   k_col      reads a column tile of T1, DCT-II along the columns, semi-implicit spectral
+//              update of the carried hat_U (solver.py:201-206, utils.py:39-49 formed from
+//              the 1-D lambda table), DCT-III along the columns, writes T2
+//                                                                   [2 reads + 2 writes]
+//   k_row_inv  reads T2 rows, DCT-III along the row, writes U (solver.py:208)
+//                                                                   [1 read + 1 write]
+// = the 8 full-array transfers per timestep of SURVEY.md section 8(d).
+//
+// HBM layouts.  U is row-major (it is the boundary's array).  T1/T2 are "column-tile
+// major": element (r, k) lives at ((k / C) * N + r) * C + (k % C) with C = 256/G columns
+// per tile, so a column tile is one contiguous slab (k_col streams it with 16-byte
+// coalesced accesses through an LDS stage) while the row kernels touch it in C*8-byte
+// pieces, four consecutive rows (one workgroup) completing each 128-byte line.
+// hat_U lives in k_col's native order: for column kc, position p of lane l at
+// kc*N + p*G + l -- nobody else reads it.
+#include <cmath>
+#include <vector>
+
 #include "chs_common.h"
-bool chs_fast_supported(int N, int dtype) { (void)N; (void)dtype; return false; }
-int chs_fast_init(Engine* E) { (void)E; chs_set_error("fast engine not built"); return CHS_EINVAL; }
-void chs_fast_free(Engine* E) { (void)E; }
-int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse) { (void)E; (void)in; (void)out; (void)inverse; return CHS_EINVAL; }
-int chs_fast_enter(Engine* E) { (void)E; return CHS_EINVAL; }
-int chs_fast_step(Engine* E) { (void)E; return CHS_EINVAL; }
+#include "chs_fast_core.h"
+#include "chs_math.h"
+
+enum { MODE_STEP = 0, MODE_FWD_NATIVE = 1, MODE_FWD_NATURAL = 2, MODE_INV_NATURAL = 3 };
+
+template <class C>
+__device__ __forceinline__ size_t tile_addr(int r, int k) {
+  return ((size_t)(k / C::C) * C::N + r) * C::C + (k % C::C);
+}
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, T q[4]) {
+  if constexpr (sizeof(T) == 8) {
+    const double2 a = *reinterpret_cast<const double2*>(p);
+    const double2 b = *reinterpret_cast<const double2*>(p + 2);
+    q[0] = a.x; q[1] = a.y; q[2] = b.x; q[3] = b.y;
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const T q[4]) {
+  if constexpr (sizeof(T) == 8) {
+    *reinterpret_cast<double2*>(p) = make_double2(q[0], q[1]);
+    *reinterpret_cast<double2*>(p + 2) = make_double2(q[2], q[3]);
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(q[0], q[1], q[2], q[3]);
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
+
+// ---------------------------------------------------------------------------
+// k_row_fwd: one group per row.  POINTWISE: the operand is EnergieEut(U) and the
+// block's sum(mu^2) is recorded (solver.py:225); otherwise a plain transform.
+// ---------------------------------------------------------------------------
+template <class C, bool POINTWISE>
+__global__ __launch_bounds__(256) void k_row_fwd(const typename C::T* __restrict__ U, typename C::T* __restrict__ T1,
+                                                 FTables<typename C::T> tb, DevConsts dc,
+                                                 const DevState* __restrict__ st, double* __restrict__ partMu) {
+  using T = typename C::T;
+  __shared__ double red[32];
+  if (st->halt) return;
+  T* lds = reinterpret_cast<T*>(chs_dyn_lds);
+  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
+  const int row = blockIdx.x * C::C + sub;
+  T* scr = lds + (size_t)sub * C::SCR;
+  T re[C::E], im[C::E];
+  double s2 = 0.0;
+  const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
+  const T* urow = U + (size_t)row * C::N;
+#pragma unroll
+  for (int q = 0; q < C::NP0; ++q) {
+    const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+    for (int j = 0; j < C::R0 / 2; ++j) {
+      T q1[4], q2[4];
+      load4<T>(urow + 4 * (size_t)(m1 + C::L1 * j), q1);
+      load4<T>(urow + 4 * (size_t)(m2 + C::L1 * j), q2);
+      if constexpr (POINTWISE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          q1[e] = chs_mu<T>(q1[e], RT, BRT, A0, A1);
+          q2[e] = chs_mu<T>(q2[e], RT, BRT, A0, A1);
+          s2 += (double)q1[e] * (double)q1[e] + (double)q2[e] * (double)q2[e];
+        }
+      }
+      pack_quads<C>(q1, q2, q, j, re, im);
+    }
+  }
+  T out[2 * C::E];
+  fwd_transform<C>(re, im, out, scr, tb, l);
+#pragma unroll
+  for (int q = 0; q < C::NP2; ++q)
+#pragma unroll
+    for (int k = 0; k < C::R2; ++k)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, Own<C>::out_index(l, q, k, t))] = out[(q * C::R2 + k) * 4 + t];
+  if constexpr (POINTWISE) {
+    const double tot = block_sum(s2, red);
+    if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_row_inv: one group per row: T2 (tile-major) -> DCT-III -> U (row-major).
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
+                                                 FTables<typename C::T> tb, const DevState* __restrict__ st) {
+  using T = typename C::T;
+  if (st->halt) return;
+  T* lds = reinterpret_cast<T*>(chs_dyn_lds);
+  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
+  const int row = blockIdx.x * C::C + sub;
+  T* scr = lds + (size_t)sub * C::SCR;
+  T out[2 * C::E];
+#pragma unroll
+  for (int q = 0; q < C::NP2; ++q)
+#pragma unroll
+    for (int k = 0; k < C::R2; ++k)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) out[(q * C::R2 + k) * 4 + t] = T2[tile_addr<C>(row, Own<C>::out_index(l, q, k, t))];
+  T re[C::E], im[C::E];
+  inv_transform<C>(out, re, im, scr, tb, l);
+  T* urow = U + (size_t)row * C::N;
+#pragma unroll
+  for (int q = 0; q < C::NP0; ++q) {
+    const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+    for (int j = 0; j < C::R0 / 2; ++j) {
+      T q1[4], q2[4];
+      unpack_quads<C>(re, im, q, j, q1, q2);
+      store4<T>(urow + 4 * (size_t)(m1 + C::L1 * j), q1);
+      store4<T>(urow + 4 * (size_t)(m2 + C::L1 * j), q2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_col: one workgroup per column tile (C columns, one group each).
+// The tile (N rows x C columns, contiguous) is staged through LDS in two rounds of
+// N/2 rows so that HBM sees only 16-byte coalesced accesses.
+// ---------------------------------------------------------------------------
+template <class C>
+struct ColStage {
+  static constexpr int LINE = 4 * C::C;        // elements per 4-row line of the tile
+  static constexpr int LP = LINE + 1;          // padded line pitch in LDS (conflict-free quad reads)
+  static constexpr int LINES = C::M / 4;       // lines per round
+  static constexpr int ELEMS = LINES * LP;     // staging elements
+  static constexpr int JR = C::R0 / 4;         // pass-0 half-indices j per round
+  static_assert(C::R0 >= 4, "pass-0 radix must be >= 4");
+};
+
+template <class C>
+constexpr int col_lds_elems() {
+  return (C::C * C::SCR > ColStage<C>::ELEMS) ? C::C * C::SCR : ColStage<C>::ELEMS;
+}
+
+template <class C, int MODE>
+__global__ __launch_bounds__(256) void k_col(const typename C::T* __restrict__ Tin, typename C::T* __restrict__ Tout,
+                                             typename C::T* __restrict__ hat, typename C::T* __restrict__ nat,
+                                             FTables<typename C::T> tb, const double* __restrict__ lam,
+                                             DevState* __restrict__ st) {
+  using T = typename C::T;
+  using CS = ColStage<C>;
+  if (st->halt) return;
+  T* lds = reinterpret_cast<T*>(chs_dyn_lds);
+  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
+  const int ct = blockIdx.x;
+  const int kc = ct * C::C + sub;  // this group's column
+  T* scr = lds + (size_t)sub * C::SCR;
+  T re[C::E], im[C::E];
+  T out[2 * C::E];
+
+  if constexpr (MODE != MODE_INV_NATURAL) {
+    // ---- stage in: tile rows -> quads of this group's column
+    const T* tile = Tin + (size_t)ct * C::N * C::C;
+#pragma unroll
+    for (int rho = 0; rho < 2; ++rho) {
+      __syncthreads();
+      const T* src = tile + (size_t)rho * CS::LINES * CS::LINE;
+      for (int f = 2 * threadIdx.x; f < CS::LINES * CS::LINE; f += 2 * 256) {
+        T a, b;
+        if constexpr (sizeof(T) == 8) {
+          const double2 v = *reinterpret_cast<const double2*>(src + f);
+          a = v.x; b = v.y;
+        } else {
+          const float2 v = *reinterpret_cast<const float2*>(src + f);
+          a = v.x; b = v.y;
+        }
+        const int line = f / CS::LINE, off = f % CS::LINE;
+        lds[line * CS::LP + off] = a;
+        lds[line * CS::LP + off + 1] = b;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < C::NP0; ++q) {
+        const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+        for (int jj = 0; jj < CS::JR; ++jj) {
+          const int j = rho * CS::JR + jj;
+          T q1[4], q2[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            q1[e] = lds[(m1 + C::L1 * jj) * CS::LP + e * C::C + sub];
+            q2[e] = lds[(m2 + C::L1 * jj) * CS::LP + e * C::C + sub];
+          }
+          pack_quads<C>(q1, q2, q, j, re, im);
+        }
+      }
+    }
+    __syncthreads();
+    fwd_transform<C>(re, im, out, scr, tb, l);
+  }
+
+  // ---- spectral stage on this lane's coefficients
+  T* hcol = hat + (size_t)kc * C::N;
+  const double lam1 = st->lam1, lam2 = st->lam2;
+  const double lc = lam[kc];
+#pragma unroll
+  for (int q = 0; q < C::NP2; ++q)
+#pragma unroll
+    for (int k = 0; k < C::R2; ++k)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int p = (q * C::R2 + k) * 4 + t;
+        const int kr = Own<C>::out_index(l, q, k, t);
+        if constexpr (MODE == MODE_STEP) {
+          const T h = chs_spectral<T>(hcol[(size_t)p * C::G + l], out[p], lam[kr], lc, lam1, lam2);
+          hcol[(size_t)p * C::G + l] = h;
+          out[p] = h;
+          if (kr == 0 && kc == 0) st->meanU = (double)h / (double)C::N;
+        } else if constexpr (MODE == MODE_FWD_NATIVE) {
+          hcol[(size_t)p * C::G + l] = out[p];
+        } else if constexpr (MODE == MODE_FWD_NATURAL) {
+          nat[(size_t)kr * C::N + kc] = out[p];
+        } else {
+          out[p] = nat[(size_t)kr * C::N + kc];
+        }
+      }
+
+  if constexpr (MODE == MODE_STEP || MODE == MODE_INV_NATURAL) {
+    inv_transform<C>(out, re, im, scr, tb, l);
+    // ---- stage out: quads -> tile rows
+    T* tile = Tout + (size_t)ct * C::N * C::C;
+#pragma unroll
+    for (int rho = 0; rho < 2; ++rho) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < C::NP0; ++q) {
+        const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+        for (int jj = 0; jj < CS::JR; ++jj) {
+          const int j = rho * CS::JR + jj;
+          T q1[4], q2[4];
+          unpack_quads<C>(re, im, q, j, q1, q2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            lds[(m1 + C::L1 * jj) * CS::LP + e * C::C + sub] = q1[e];
+            lds[(m2 + C::L1 * jj) * CS::LP + e * C::C + sub] = q2[e];
+          }
+        }
+      }
+      __syncthreads();
+      T* dst = tile + (size_t)rho * CS::LINES * CS::LINE;
+      for (int f = 2 * threadIdx.x; f < CS::LINES * CS::LINE; f += 2 * 256) {
+        const int line = f / CS::LINE, off = f % CS::LINE;
+        const T a = lds[line * CS::LP + off], b = lds[line * CS::LP + off + 1];
+        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst + f) = make_double2(a, b);
+        else *reinterpret_cast<float2*>(dst + f) = make_float2(a, b);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct FastPlan {
+  int N, G, R0, R1, R2;
+  void* tables = nullptr;  // one device allocation
+  size_t off_tw0, off_tw1, off_wp, off_t1, off_t2;  // element offsets
+  int (*row_fwd)(Engine*, const void*, void*, bool) = nullptr;
+  int (*row_inv)(Engine*, const void*, void*) = nullptr;
+  int (*col)(Engine*, int, const void*, void*, void*, void*) = nullptr;
+  int (*init)(Engine*) = nullptr;
+};
+
+template <typename T>
+static FTables<T> get_tables(Engine* E) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  const T* base = (const T*)P->tables;
+  FTables<T> tb;
+  tb.tw0 = base + P->off_tw0; tb.tw1 = base + P->off_tw1; tb.wp = base + P->off_wp;
+  tb.t1 = base + P->off_t1; tb.t2 = base + P->off_t2;
+  return tb;
+}
+
+template <class C>
+struct Launch {
+  using T = typename C::T;
+  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T);
+  static constexpr size_t col_lds = (size_t)col_lds_elems<C>() * sizeof(T);
+
+  static int init(Engine* E) {
+    (void)E;
+    CHS_HIP(hipFuncSetAttribute((const void*)k_row_fwd<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds));
+    CHS_HIP(hipFuncSetAttribute((const void*)k_row_fwd<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds));
+    CHS_HIP(hipFuncSetAttribute((const void*)k_row_inv<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds));
+    CHS_HIP(hipFuncSetAttribute((const void*)k_col<C, MODE_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds));
+    CHS_HIP(hipFuncSetAttribute((const void*)k_col<C, MODE_FWD_NATIVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds));
+    CHS_HIP(hipFuncSetAttribute((const void*)k_col<C, MODE_FWD_NATURAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds));
+    CHS_HIP(hipFuncSetAttribute((const void*)k_col<C, MODE_INV_NATURAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds));
+    return CHS_OK;
+  }
+  static int row_fwd(Engine* E, const void* in, void* out, bool pointwise) {
+    const int grid = C::N / C::C;
+    if (pointwise)
+      k_row_fwd<C, true><<<grid, 256, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
+                                                            E->dPartMu);
+    else
+      k_row_fwd<C, false><<<grid, 256, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
+                                                             E->dPartMu);
+    CHS_HIP(hipGetLastError());
+    return CHS_OK;
+  }
+  static int row_inv(Engine* E, const void* in, void* out) {
+    const int grid = C::N / C::C;
+    k_row_inv<C><<<grid, 256, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dState);
+    CHS_HIP(hipGetLastError());
+    return CHS_OK;
+  }
+  static int col(Engine* E, int mode, const void* tin, void* tout, void* hat, void* nat) {
+    const int grid = C::N / C::C;
+    const FTables<T> tb = get_tables<T>(E);
+    switch (mode) {
+      case MODE_STEP:
+        k_col<C, MODE_STEP><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dState);
+        break;
+      case MODE_FWD_NATIVE:
+        k_col<C, MODE_FWD_NATIVE><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dState);
+        break;
+      case MODE_FWD_NATURAL:
+        k_col<C, MODE_FWD_NATURAL><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dState);
+        break;
+      default:
+        k_col<C, MODE_INV_NATURAL><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dState);
+        break;
+    }
+    CHS_HIP(hipGetLastError());
+    return CHS_OK;
+  }
+};
+
+// fp64 configurations: N -> (G, R0, R1, R2, pad1, pad2)
+using F128 = FCfg<double, 128, 4, 8, 1, 8, 0, 1>;
+using F256 = FCfg<double, 256, 8, 8, 2, 8, 1, 1>;
+using F512 = FCfg<double, 512, 16, 8, 4, 8, 1, 1>;
+using F1024 = FCfg<double, 1024, 32, 8, 8, 8, 2, 8>;
+using F2048 = FCfg<double, 2048, 64, 8, 16, 8, 2, 8>;
+using F4096 = FCfg<double, 4096, 64, 16, 8, 16, 2, 16>;
+
+template <class C>
+static void bind(FastPlan* P) {
+  P->N = C::N; P->G = C::G; P->R0 = C::R0; P->R1 = C::R1; P->R2 = C::R2;
+  P->row_fwd = &Launch<C>::row_fwd;
+  P->row_inv = &Launch<C>::row_inv;
+  P->col = &Launch<C>::col;
+  P->init = &Launch<C>::init;
+}
+
+bool chs_fast_supported(int N, int dtype) {
+  if (dtype != CHS_F64) return false;
+  return N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096;
+}
+
+static void twiddle(long double num, long double den, long double& c, long double& s) {
+  // exp(-2 pi i num/den) = c - i s, argument reduced exactly
+  static const long double PI = 3.14159265358979323846264338327950288419716939937510L;
+  const long double a = 2.0L * PI * (num / den);
+  c = cosl(a); s = sinl(a);
+}
+
+template <typename T>
+static int build_tables(Engine* E, FastPlan* P) {
+  const int N = P->N, M = N / 2, L1 = M / P->R0, L2 = L1 / P->R1;
+  std::vector<T> h;
+  auto push = [&](long double r, long double i) { h.push_back((T)r); h.push_back((T)i); };
+  P->off_tw0 = h.size();
+  for (int k = 1; k < P->R0; ++k)
+    for (int m = 0; m < L1; ++m) {
+      long double c, s;
+      twiddle((long double)(((long long)m * k) % M), (long double)M, c, s);
+      push(c, -s);
+    }
+  P->off_tw1 = h.size();
+  for (int k = 1; k < P->R1; ++k)
+    for (int m = 0; m < L2; ++m) {
+      long double c, s;
+      twiddle((long double)(((long long)m * k) % L1), (long double)L1, c, s);
+      push(c, -s);
+    }
+  static const long double PI = 3.14159265358979323846264338327950288419716939937510L;
+  P->off_wp = h.size();
+  for (int kk = 0; kk <= M; ++kk) {  // -i exp(-2 pi i kk/N) = -sin(th) - i cos(th)
+    const long double th = 2.0L * PI * (long double)kk / (long double)N;
+    push(-sinl(th), -cosl(th));
+  }
+  auto Tk = [&](int k, long double& r, long double& i) {  // s_k/2 exp(-i pi k/(2N))
+    const long double s = (k == 0) ? sqrtl(1.0L / N) : sqrtl(2.0L / N);
+    const long double ph = PI * (long double)k / (2.0L * N);
+    r = 0.5L * s * cosl(ph); i = -0.5L * s * sinl(ph);
+  };
+  P->off_t1 = h.size();
+  for (int kk = 0; kk <= M; ++kk) { long double r, i; Tk(kk, r, i); push(r, i); }
+  P->off_t2 = h.size();
+  for (int kk = 0; kk <= M; ++kk) { long double r, i; Tk(M - kk, r, i); push(r, -i); }
+  CHS_HIP(hipMalloc(&P->tables, h.size() * sizeof(T)));
+  CHS_HIP(hipMemcpy(P->tables, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  (void)E;
+  return CHS_OK;
+}
+
+int chs_fast_init(Engine* E) {
+  FastPlan* P = new FastPlan();
+  switch (E->N) {
+    case 128: bind<F128>(P); break;
+    case 256: bind<F256>(P); break;
+    case 512: bind<F512>(P); break;
+    case 1024: bind<F1024>(P); break;
+    case 2048: bind<F2048>(P); break;
+    case 4096: bind<F4096>(P); break;
+    default: delete P; chs_set_error("fast engine: unsupported N"); return CHS_EINVAL;
+  }
+  E->dTw = P;
+  int rc = build_tables<double>(E, P);
+  if (rc) return rc;
+  if ((rc = P->init(E))) return rc;
+  // k_row_fwd writes one sum(mu^2) partial per workgroup
+  E->nPartMu = E->N / (256 / P->G);
+  return CHS_OK;
+}
+
+void chs_fast_free(Engine* E) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  if (!P) return;
+  if (P->tables) hipFree(P->tables);
+  delete P;
+  E->dTw = nullptr;
+}
+
+int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  int rc;
+  if (!inverse) {
+    if ((rc = P->row_fwd(E, in, E->dT1, false))) return rc;
+    return P->col(E, MODE_FWD_NATURAL, E->dT1, nullptr, E->dHat, out);
+  }
+  if ((rc = P->col(E, MODE_INV_NATURAL, nullptr, E->dT1, E->dHat, (void*)in))) return rc;
+  return P->row_inv(E, E->dT1, out);
+}
+
+int chs_fast_enter(Engine* E) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  int rc;
+  if ((rc = P->row_fwd(E, E->dU, E->dT1, false))) return rc;
+  return P->col(E, MODE_FWD_NATIVE, E->dT1, nullptr, E->dHat, nullptr);
+}
+
+int chs_fast_step(Engine* E) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  int rc;
+  if (E->dc.adaptive_time) {
+    // column sums of the adaptive-step integrand (solver.py:183) on the steps that need them
+    if ((rc = chs_launch_mu_colsums(E))) return rc;
+  }
+  chs_slot_begin(E, SLOT_MU);
+  rc = P->row_fwd(E, E->dU, E->dT1, true);
+  chs_slot_end(E, SLOT_MU);
+  if (rc) return rc;
+  if ((rc = chs_launch_pre(E))) return rc;
+  chs_slot_begin(E, SLOT_SPEC);
+  rc = P->col(E, MODE_STEP, E->dT1, E->dT2, E->dHat, nullptr);
+  chs_slot_end(E, SLOT_SPEC);
+  if (rc) return rc;
+  chs_slot_begin(E, SLOT_INV);
+  rc = P->row_inv(E, E->dT2, E->dU);
+  chs_slot_end(E, SLOT_INV);
+  return rc;
+}

@@ -22,14 +22,14 @@
 template <typename T>
 __global__ __launch_bounds__(PW_THREADS) void k_mu(const T* __restrict__ U, T* __restrict__ MU, DevConsts dc,
                                                    const DevState* __restrict__ st, double* __restrict__ partMu,
-                                                   double* __restrict__ partCol, int force_col) {
+                                                   double* __restrict__ partCol, int only_col) {
   __shared__ double scratch[32];
   if (st->halt) return;
   const int N = dc.N;
   const int r0 = blockIdx.x * PW_BAND;
   const int r1 = min(r0 + PW_BAND, N);
-  const bool want_col =
-      force_col || (dc.adaptive_time && st->computed_steps > 500 && (st->computed_steps % 2) == 0);
+  const bool want_col = (dc.adaptive_time && st->computed_steps > 500 && (st->computed_steps % 2) == 0);
+  if (only_col && !want_col) return;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
   double s2 = 0.0;
   for (int c = threadIdx.x; c < N; c += PW_THREADS) {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(PW_THREADS) void k_mu(const T* __restrict__ U, T* _
     for (int r = r0; r < r1; ++r) {
       const T u = U[(size_t)r * N + c];
       const T m = chs_mu<T>(u, RT, BRT, A0, A1);
-      MU[(size_t)r * N + c] = m;
+      if (!only_col) MU[(size_t)r * N + c] = m;
       const double md = (double)m;
       s2 += md * md;
       if (want_col) cs += chs_dt_integrand(md, dc.delt_max);
@@ -318,9 +318,11 @@ __global__ __launch_bounds__(PW_THREADS) void k_jitter(T* __restrict__ U, const 
 int chs_pointwise_alloc(Engine* E) {
   const int N = E->N;
   E->nBands = (N + PW_BAND - 1) / PW_BAND;
+  E->nPartMu = E->nBands;
   E->nDiagBlocks = E->nBands;
   E->nColMinBlocks = (N + PW_THREADS - 1) / PW_THREADS;
-  CHS_HIP(hipMalloc(&E->dPartMu, sizeof(double) * (size_t)E->nBands));
+  CHS_HIP(hipMalloc(&E->dPartMu, sizeof(double) * (size_t)(E->nBands > N ? E->nBands : N)));
+  CHS_HIP(hipMalloc(&E->dPartMuAux, sizeof(double) * (size_t)E->nBands));
   CHS_HIP(hipMalloc(&E->dPartDiag, sizeof(double) * 4 * (size_t)E->nDiagBlocks));
   CHS_HIP(hipMalloc(&E->dPartSum, sizeof(double) * (size_t)E->nBands));
   CHS_HIP(hipMalloc(&E->dPartColMin, sizeof(double) * (size_t)E->nColMinBlocks));
@@ -328,7 +330,7 @@ int chs_pointwise_alloc(Engine* E) {
   return CHS_OK;
 }
 void chs_pointwise_free(Engine* E) {
-  hipFree(E->dPartMu); hipFree(E->dPartDiag); hipFree(E->dPartSum);
+  hipFree(E->dPartMu); hipFree(E->dPartMuAux); hipFree(E->dPartDiag); hipFree(E->dPartSum);
   hipFree(E->dPartColMin); hipFree(E->dPartCol);
 }
 
@@ -347,12 +349,24 @@ int chs_launch_mu(Engine* E) {
   return CHS_OK;
 }
 
+int chs_launch_mu_colsums(Engine* E) {
+  chs_slot_begin(E, SLOT_MISC);
+  DISPATCH_T(E,
+    (k_mu<double><<<E->nBands, PW_THREADS, 0, E->stream>>>((const double*)E->dU, (double*)E->dMU, E->dc, E->dState,
+                                                            E->dPartMuAux, E->dPartCol, 1)),
+    (k_mu<float><<<E->nBands, PW_THREADS, 0, E->stream>>>((const float*)E->dU, (float*)E->dMU, E->dc, E->dState,
+                                                           E->dPartMuAux, E->dPartCol, 1)));
+  chs_slot_end(E, SLOT_MISC);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
 int chs_launch_pre(Engine* E) {
   chs_slot_begin(E, SLOT_PRE);
   if (E->dc.adaptive_time)
     k_colmin<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dPartCol, E->nBands, E->N, E->dState,
                                                               E->dc.adaptive_time, E->dPartColMin);
-  k_pre<<<1, PW_THREADS, 0, E->stream>>>(E->dc, E->dState, E->dPartMu, E->nBands, E->dPartColMin,
+  k_pre<<<1, PW_THREADS, 0, E->stream>>>(E->dc, E->dState, E->dPartMu, E->nPartMu, E->dPartColMin,
                                          E->nColMinBlocks);
   chs_slot_end(E, SLOT_PRE);
   CHS_HIP(hipGetLastError());

@@ -54,7 +54,8 @@ def compare_run(p, okw, U_init=None, rtol=RTOL, cols=(1, 2, 3, 4, 5, 6, 7, 8)):
     return sol, o
 
 
-@pytest.mark.parametrize("engine,N", [('direct', 64), ('direct', 100), ('direct', 128), ('fast', 128), ('fast', 256)])
+@pytest.mark.parametrize("engine,N", [('direct', 64), ('direct', 100), ('direct', 128), ('fast', 128), ('fast', 256),
+                                      ('fast', 512), ('fast', 1024), ('fast', 2048), ('fast', 4096)])
 def test_dctn_matches_scipy(gpu, engine, N):
     p = make(N, 2, engine)
     s = chsimpy_amd.Solver(p)
