@@ -26,7 +26,7 @@ DTYPES = {'float64': CHS_F64, 'f64': CHS_F64, 'float32': CHS_F32, 'f32': CHS_F32
 # every symbol include/chs_hip.h declares
 SYMBOLS = (
     'chs_create', 'chs_destroy', 'chs_set_U', 'chs_get_U', 'chs_prepare', 'chs_step_n',
-    'chs_get_state', 'chs_set_state', 'chs_set_jitter_noise', 'chs_dctn', 'chs_get_mu',
+    'chs_get_state', 'chs_set_state', 'chs_set_jitter_noise', 'chs_dctn', 'chs_get_mu', 'chs_test_math',
     'chs_engine', 'chs_kernel_name', 'chs_profile_steps', 'chs_last_step_ms',
     'chs_last_error', 'chs_version',
 )
@@ -80,6 +80,7 @@ def load():
     lib.chs_dctn.argtypes = [C.c_void_p, dp, dp, C.c_int]
     lib.chs_get_mu.argtypes = [C.c_void_p, dp]
     lib.chs_engine.argtypes = [C.c_void_p]
+    lib.chs_test_math.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_int64]
     lib.chs_kernel_name.argtypes = [C.c_void_p, C.c_int]
     lib.chs_kernel_name.restype = C.c_char_p
     lib.chs_profile_steps.argtypes = [C.c_void_p, C.c_int64, dp, C.POINTER(C.c_int64)]
@@ -104,6 +105,20 @@ def _as_f64(a, shape=None):
     if shape is not None and a.shape != shape:
         raise ValueError(f"expected shape {shape}, got {a.shape}")
     return a
+
+
+def test_math(which, a, b=None, device=0):
+    """Device math primitives (accuracy tests): see chs_test_math in include/chs_hip.h."""
+    lib = load()
+    a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+    out = np.empty_like(a)
+    if b is None:
+        b = np.zeros(4)
+    b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+    rc = lib.chs_test_math(device, which, _dptr(a), _dptr(b), _dptr(out), a.size)
+    if rc != CHS_OK:
+        raise EngineError(f"chs_test_math failed ({rc}): {lib.chs_last_error().decode()}")
+    return out
 
 
 class Engine:

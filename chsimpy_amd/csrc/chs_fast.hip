@@ -59,7 +59,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 // block's sum(mu^2) is recorded (solver.py:225); otherwise a plain transform.
 // ---------------------------------------------------------------------------
 template <class C, bool POINTWISE>
-__global__ __launch_bounds__(256) void k_row_fwd(const typename C::T* __restrict__ U, typename C::T* __restrict__ T1,
+__global__ __launch_bounds__(256, 2) void k_row_fwd(const typename C::T* __restrict__ U, typename C::T* __restrict__ T1,
                                                  FTables<typename C::T> tb, DevConsts dc,
                                                  const DevState* __restrict__ st, double* __restrict__ partMu) {
   using T = typename C::T;
@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void k_row_fwd(const typename C::T* __restrict
   double s2 = 0.0;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
   const T* urow = U + (size_t)row * C::N;
+  // all loads first (they stay in flight together), then the pointwise term quad by quad:
+  // the scheduling barriers keep the compiler from interleaving 64 inlined logarithms,
+  // which would not fit the register budget of two waves per SIMD
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
     const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
@@ -81,15 +84,16 @@ __global__ __launch_bounds__(256) void k_row_fwd(const typename C::T* __restrict
       T q1[4], q2[4];
       load4<T>(urow + 4 * (size_t)(m1 + C::L1 * j), q1);
       load4<T>(urow + 4 * (size_t)(m2 + C::L1 * j), q2);
-      if constexpr (POINTWISE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          q1[e] = chs_mu<T>(q1[e], RT, BRT, A0, A1);
-          q2[e] = chs_mu<T>(q2[e], RT, BRT, A0, A1);
-          s2 += (double)q1[e] * (double)q1[e] + (double)q2[e] * (double)q2[e];
-        }
-      }
       pack_quads<C>(q1, q2, q, j, re, im);
+    }
+  }
+  if constexpr (POINTWISE) {
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) {
+      re[e] = chs_mu<T>(re[e], RT, BRT, A0, A1);
+      im[e] = chs_mu<T>(im[e], RT, BRT, A0, A1);
+      s2 += (double)re[e] * (double)re[e] + (double)im[e] * (double)im[e];
+      if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
   T out[2 * C::E];
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void k_row_fwd(const typename C::T* __restrict
 // k_row_inv: one group per row: T2 (tile-major) -> DCT-III -> U (row-major).
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
+__global__ __launch_bounds__(256, 2) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
                                                  FTables<typename C::T> tb, const DevState* __restrict__ st) {
   using T = typename C::T;
   if (st->halt) return;
@@ -162,7 +166,7 @@ constexpr int col_lds_elems() {
 }
 
 template <class C, int MODE>
-__global__ __launch_bounds__(256) void k_col(const typename C::T* __restrict__ Tin, typename C::T* __restrict__ Tout,
+__global__ __launch_bounds__(256, 2) void k_col(const typename C::T* __restrict__ Tin, typename C::T* __restrict__ Tout,
                                              typename C::T* __restrict__ hat, typename C::T* __restrict__ nat,
                                              FTables<typename C::T> tb, const double* __restrict__ lam,
                                              DevState* __restrict__ st) {
@@ -241,6 +245,9 @@ __global__ __launch_bounds__(256) void k_col(const typename C::T* __restrict__ T
           nat[(size_t)kr * C::N + kc] = out[p];
         } else {
           out[p] = nat[(size_t)kr * C::N + kc];
+        }
+        if constexpr (MODE == MODE_STEP) {
+          if (t == 3 && (k & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight
         }
       }
 

@@ -190,9 +190,19 @@ __device__ __forceinline__ void ldc(const T* __restrict__ tab, int idx, T& r, T&
   }
 }
 
-// Group-level synchronisation of the LDS exchange.  A group lives inside one wavefront,
-// but the first version keeps the whole workgroup in step (simple and safe).
-__device__ __forceinline__ void xsync() { __syncthreads(); }
+// Group-level synchronisation of the LDS exchange.  A group never spans wavefronts and
+// the LDS executes one wave's accesses in issue order, so no s_barrier is needed: the
+// wavefront-scope fences only keep the COMPILER from moving LDS accesses across the point
+// where other lanes of the same wave take over the data.
+__device__ __forceinline__ void xsync() {
+#ifdef CHS_XSYNC_BLOCK
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // ownership helpers (runtime, per lane)

@@ -6,9 +6,89 @@
 #include <hip/hip_runtime.h>
 #include "chs_common.h"
 
+// ---------------------------------------------------------------------------
+// fp64 logarithms.  ocml's log() is a ~100-instruction double-double routine; the
+// timestep needs three logs per grid point, which would make the loop VALU-bound.
+// These are lean (< 1.5 ulp measured on gfx950, tests/test_gpu_math.py) versions:
+//   log(q) = 2 atanh(s), s = (q-1)/(q+1), |s| <= 0.1716 after reduction to
+//   q in [sqrt(1/2), sqrt(2)];  log(q) = 2s + s*z*P(z), z = s^2, P of degree 6
+//   (tools/log_poly.py, approximation error 6e-18).
+// Domain handling follows numpy: log(0) = -inf, log(x<0) = NaN, NaN stays NaN, so
+// that a field leaving (0,1) still surfaces as the NaN assertion of timedata.py:10.
+// ---------------------------------------------------------------------------
+#define CHS_LN2_HI 0.6931471803691238      /* 0x1.62e42fee00000p-1 (21 trailing zero bits) */
+#define CHS_LN2_LO 1.9082149292705877e-10
+#define CHS_SQRT2 1.4142135623730951
+#define CHS_SQRT1_2 0.7071067811865476
+
+// d / sig for sig in [0.5, 4): hardware reciprocal + two Newton steps + one residual correction
+__device__ __forceinline__ double chs_div_pos(double d, double sig) {
+  double r = __builtin_amdgcn_rcp(sig);
+  double e = __builtin_fma(-sig, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-sig, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q = d * r;
+  const double rho = __builtin_fma(-sig, q, d);
+  return __builtin_fma(rho, r, q);
+}
+
+// s -> 2 atanh(s) for |s| <= 0.1716
+__device__ __forceinline__ double chs_log_poly(double s) {
+  const double z = s * s;
+  double p = 0.1467141530063111;
+  p = __builtin_fma(p, z, 0.15327184863231447);
+  p = __builtin_fma(p, z, 0.18183028385247743);
+  p = __builtin_fma(p, z, 0.22222209184316374);
+  p = __builtin_fma(p, z, 0.2857142863817006);
+  p = __builtin_fma(p, z, 0.3999999999987206);
+  p = __builtin_fma(p, z, 0.6666666666666671);
+  return __builtin_fma(s * z, p, s + s);
+}
+
+// log(x)
+__device__ __forceinline__ double chs_log_f64(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const int c = (m < CHS_SQRT1_2) ? 1 : 0;
+  m = __builtin_ldexp(m, c);                  // [sqrt(1/2), sqrt(2))
+  e -= c;
+  const double s = chs_div_pos(m - 1.0, m + 1.0);
+  const double lq = chs_log_poly(s);
+  const double k = (double)e;
+  double res = __builtin_fma(k, CHS_LN2_HI, __builtin_fma(k, CHS_LN2_LO, lq));
+  res = (x > 0.0) ? res : ((x == 0.0) ? -__builtin_inf() : __builtin_nan(""));
+  res = (x == __builtin_inf()) ? x : res;
+  return res;
+}
+
+// log(a / b) without forming the quotient
+__device__ __forceinline__ double chs_log_ratio_f64(double a, double b) {
+  double ma = __builtin_amdgcn_frexp_mant(a), mb = __builtin_amdgcn_frexp_mant(b);  // [0.5, 1)
+  const int ea = __builtin_amdgcn_frexp_exp(a), eb = __builtin_amdgcn_frexp_exp(b);
+  const int c1 = (ma > CHS_SQRT2 * mb) ? 1 : 0;   // q > sqrt2  -> halve q
+  const int c2 = (CHS_SQRT2 * ma < mb) ? 1 : 0;   // q < 1/sqrt2 -> double q
+  mb = __builtin_ldexp(mb, c1);
+  ma = __builtin_ldexp(ma, c2);
+  const int e = ea - eb + c1 - c2;
+  const double s = chs_div_pos(ma - mb, ma + mb);  // ma - mb is exact (Sterbenz)
+  const double lq = chs_log_poly(s);
+  const double k = (double)e;
+  double res = __builtin_fma(k, CHS_LN2_HI, __builtin_fma(k, CHS_LN2_LO, lq));
+  // numpy gives NaN / -inf / +inf for a quotient that is negative / 0 / x/0; all of them
+  // poison the step and trip the reference's NaN assertion, so one NaN covers them
+  const bool ok = (a > 0.0) && (b > 0.0) && (a < __builtin_inf()) && (b < __builtin_inf());
+  return ok ? res : __builtin_nan("");  // every non-finite case ends in the NaN assertion anyway
+}
+
 template <typename T> __device__ __forceinline__ T chs_log(T x);
-template <> __device__ __forceinline__ double chs_log<double>(double x) { return log(x); }
+template <> __device__ __forceinline__ double chs_log<double>(double x) { return chs_log_f64(x); }
 template <> __device__ __forceinline__ float chs_log<float>(float x) { return logf(x); }
+
+// log(U / Uinv)
+template <typename T> __device__ __forceinline__ T chs_log_ratio(T a, T b);
+template <> __device__ __forceinline__ double chs_log_ratio<double>(double a, double b) { return chs_log_ratio_f64(a, b); }
+template <> __device__ __forceinline__ float chs_log_ratio<float>(float a, float b) { return logf(a / b); }
 
 // EnergieEut, chsimpy/solver.py:166-175:
 //   Uinv = 1-U; U1Uinv = U/Uinv; U2inv = Uinv-U
@@ -17,9 +97,8 @@ template <typename T>
 __device__ __forceinline__ T chs_mu(T U, T RT, T BRT, T A0, T A1) {
 #pragma clang fp contract(off)
   const T Uinv = T(1) - U;
-  const T U1Uinv = U / Uinv;
   const T U2inv = Uinv - U;
-  const T t1 = RT * chs_log<T>(U1Uinv);
+  const T t1 = RT * chs_log_ratio<T>(U, Uinv);  // log(U / Uinv)
   const T t2 = (A0 + A1 * U2inv) * U2inv;
   const T t3 = ((T(2) * A1) * U) * Uinv;
   return ((t1 - BRT) + t2) - t3;

@@ -437,3 +437,36 @@ int chs_launch_jitter(Engine* E) {
   CHS_HIP(hipGetLastError());
   return CHS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// chs_test_math: device math primitives, elementwise (accuracy tests only)
+// ---------------------------------------------------------------------------
+__global__ void k_test_math(int which, const double* __restrict__ a, const double* __restrict__ b,
+                            double* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r;
+  if (which == 0) r = chs_log_f64(a[i]);
+  else if (which == 1) r = chs_log_ratio_f64(a[i], b[i]);
+  else if (which == 2) r = chs_mu<double>(a[i], b[0], b[1], b[2], b[3]);
+  else r = chs_energy_density<double>(a[i], b[0], b[1], b[2], b[3]);
+  out[i] = r;
+}
+
+extern "C" int chs_test_math(int device, int which, const double* a, const double* b, double* out, int64_t n) {
+  if (!a || !out || n <= 0 || which < 0 || which > 3) { chs_set_error("chs_test_math: bad argument"); return CHS_EINVAL; }
+  CHS_HIP(hipSetDevice(device));
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  const size_t nb_b = (which == 1) ? (size_t)n : 4;
+  CHS_HIP(hipMalloc(&da, sizeof(double) * n));
+  CHS_HIP(hipMalloc(&db, sizeof(double) * nb_b));
+  CHS_HIP(hipMalloc(&dout, sizeof(double) * n));
+  CHS_HIP(hipMemcpy(da, a, sizeof(double) * n, hipMemcpyHostToDevice));
+  if (b) CHS_HIP(hipMemcpy(db, b, sizeof(double) * nb_b, hipMemcpyHostToDevice));
+  k_test_math<<<(unsigned)((n + 255) / 256), 256>>>(which, da, db, dout, (long long)n);
+  CHS_HIP(hipGetLastError());
+  CHS_HIP(hipDeviceSynchronize());
+  CHS_HIP(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
+  hipFree(da); hipFree(db); hipFree(dout);
+  return CHS_OK;
+}

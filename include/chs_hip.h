@@ -141,6 +141,10 @@ int chs_set_jitter_noise(chs_handle h, double jitter, const double* host_noise);
 int chs_dctn(chs_handle h, const double* host_in, double* host_out, int inverse);
 /* EnergieEut of solver.py:166-175 for the current field. */
 int chs_get_mu(chs_handle h, double* host_mu);
+/* Device math primitives evaluated elementwise on `device` (accuracy tests):
+ * which = 0: log(a)   1: log(a/b)   2: EnergieEut(a) with (RT,BRT,A0,A1) = b[0..3]
+ *         3: bulk energy density(a) with (RT,B,A0,A1) = b[0..3]  (solver.py:218-221) */
+int chs_test_math(int device, int which, const double* a, const double* b, double* out, int64_t n);
 /* Which engine the handle resolved to (CHS_ENGINE_DIRECT / CHS_ENGINE_FAST). */
 int chs_engine(chs_handle h);
 

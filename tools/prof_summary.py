@@ -1,0 +1,49 @@
+"""Condenses a tools/prof.sh session into per-kernel averages (time + counters)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for k in ('k_row_fwd', 'k_row_inv', 'k_col', 'k_diag', 'k_fin', 'k_pre', 'k_mu', 'k_spectral', 'k_gemm', 'k_sum'):
+        if k in name:
+            if k == 'k_col':
+                # template mode is the last integer parameter
+                return k
+            return k
+    return name[:40]
+
+
+def main(d):
+    # kernel trace
+    rows = []
+    for f in glob.glob(os.path.join(d, 'trace', '**', '*kernel_trace.csv'), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    dur = defaultdict(list)
+    meta = {}
+    for r in rows:
+        n = short(r['Kernel_Name'])
+        dur[n].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        meta[n] = (r.get('VGPR_Count'), r.get('Accum_VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size'),
+                   r.get('Scratch_Size'), r.get('Grid_Size'), r.get('Workgroup_Size'))
+    print("== kernel trace (ns): name calls avg min  | vgpr agpr sgpr lds scratch grid wg")
+    for n, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        v2 = sorted(v)
+        core = v2[len(v2) // 10: max(len(v2) * 9 // 10, 1)] or v2
+        print(f"{n:14s} {len(v):6d} avg {sum(core) / len(core):10.0f} min {v2[0]:9d} | {meta[n]}")
+    # counters
+    agg = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    print("== counters (average per dispatch)")
+    for n in agg:
+        print(n)
+        for c, v in sorted(agg[n].items()):
+            print(f"    {c:28s} {sum(v) / len(v):16.1f}   (n={len(v)})")
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
