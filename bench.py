@@ -64,7 +64,7 @@ def algorithmic_bytes_per_step(N, esz):
 
 # Algorithmic transfers attributed to each per-step kernel slot.
 SLOT_TRANSFERS = {
-    'fast': {'k_row_fwd': 2, 'k_col': 4, 'k_row_inv': 2},
+    'fast': {'k_row_fwd (prologue)': 2, 'k_col': 4, 'k_row_inv (fused)': 4},
     'direct': {},
 }
 

@@ -83,6 +83,27 @@ __device__ __forceinline__ double block_min(double v, double* scratch) {
   return t;
 }
 
+// NV per-thread values -> block totals (256-thread blocks), written by thread 0 to out[0..NV).
+// One barrier, no loops with run-time trip counts: meant for the END of a register-heavy
+// kernel, where control flow around live register arrays would cost spills.
+template <int NV>
+__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* red /* >= 4*NV */,
+                                                double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double w[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) w[i] = wave_sum(v[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * NV + i] = w[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) out[i] = ((red[i] + red[NV + i]) + red[2 * NV + i]) + red[3 * NV + i];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Host-side engine object behind chs_handle.
 // ---------------------------------------------------------------------------
@@ -130,6 +151,10 @@ struct Engine {
   double* dPartColMin = nullptr;
   double* dPartDiag = nullptr; // per-block [sE, sG, sPS, cSA]
   double* dPartSum = nullptr;  // per-block sum(U)
+  double* dPartE2 = nullptr;   // per-column-tile spectral gradient sums (fast engine)
+  double* dSinSq = nullptr;    // sin^2(pi k/N), k = 0..N-1 (fast engine)
+  int nPartE2 = 0;
+  int nRowBlocks = 0;          // workgroups of the fast row kernels (diag partials)
   int nBands = 0;              // row bands used by the pointwise kernels
   int nPartMu = 0;             // number of sum(mu^2) partials the running engine produces
   double* dPartMuAux = nullptr; // scratch partials of the column-sum-only sweep
@@ -174,7 +199,7 @@ int chs_launch_pre(Engine* E);                // partials -> state (L2, delt, ti
 int chs_launch_spectral(Engine* E, const void* hmu);  // dHat <- (dHat + Seig*hmu)/CHeig (natural order)
 int chs_launch_sum(Engine* E, int ignore_halt);  // meanU <- mean(dU)
 int chs_launch_diag(Engine* E, int ignore_halt);  // dU -> diag partials
-int chs_launch_fin(Engine* E, int prepare_mode);
+int chs_launch_fin(Engine* E, int prepare_mode, int fused = 0);
 int chs_launch_jitter(Engine* E);
 int chs_pointwise_alloc(Engine* E);
 void chs_pointwise_free(Engine* E);
@@ -190,4 +215,6 @@ int chs_fast_init(Engine* E);
 void chs_fast_free(Engine* E);
 int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse);  // natural in/out (tests)
 int chs_fast_enter(Engine* E);   // hat_U <- dctn(U) in engine-native order (solver.py:159)
-int chs_fast_step(Engine* E);    // K1..K3 of one timestep (between k_pre and k_diag hooks)
+int chs_fast_prologue(Engine* E);          // T1 <- row DCT of EnergieEut(U) for the first step of a call
+int chs_fast_step(Engine* E, bool fuse_next); // k_pre, k_col, fused row kernel (+ diagnostics partials)
+int chs_fast_step_unfused(Engine* E);      // jitter path: every kernel separate, U complete in HBM

@@ -54,14 +54,23 @@ __device__ __forceinline__ void store4(T* p, const T q[4]) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 
+// Returns x through an opaque asm so that index arithmetic derived from it is not CSE'd
+// with (and kept alive since) an earlier phase of the kernel: recomputing a few integer
+// offsets is far cheaper than holding dozens of address registers across a phase.
+__device__ __forceinline__ int launder(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // ---------------------------------------------------------------------------
 // k_row_fwd: one group per row.  POINTWISE: the operand is EnergieEut(U) and the
 // block's sum(mu^2) is recorded (solver.py:225); otherwise a plain transform.
+// (Prologue of a solve_or_resume call, and the unfused/jitter path.)
 // ---------------------------------------------------------------------------
 template <class C, bool POINTWISE>
 __global__ __launch_bounds__(256, 2) void k_row_fwd(const typename C::T* __restrict__ U, typename C::T* __restrict__ T1,
-                                                 FTables<typename C::T> tb, DevConsts dc,
-                                                 const DevState* __restrict__ st, double* __restrict__ partMu) {
+                                                    FTables<typename C::T> tb, DevConsts dc,
+                                                    const DevState* __restrict__ st, double* __restrict__ partMu) {
   using T = typename C::T;
   __shared__ double red[32];
   if (st->halt) return;
@@ -73,9 +82,6 @@ __global__ __launch_bounds__(256, 2) void k_row_fwd(const typename C::T* __restr
   double s2 = 0.0;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
   const T* urow = U + (size_t)row * C::N;
-  // all loads first (they stay in flight together), then the pointwise term quad by quad:
-  // the scheduling barriers keep the compiler from interleaving 64 inlined logarithms,
-  // which would not fit the register budget of two waves per SIMD
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
     const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
@@ -93,17 +99,13 @@ __global__ __launch_bounds__(256, 2) void k_row_fwd(const typename C::T* __restr
       re[e] = chs_mu<T>(re[e], RT, BRT, A0, A1);
       im[e] = chs_mu<T>(im[e], RT, BRT, A0, A1);
       s2 += (double)re[e] * (double)re[e] + (double)im[e] * (double)im[e];
-      if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
-  T out[2 * C::E];
-  fwd_transform<C>(re, im, out, scr, tb, l);
+  fwd_passes<C>(re, im, scr, tb, l);
+  recombine<C, true, false>(re, im, tb, l, [&](int, const int idx[4], T y[4]) {
 #pragma unroll
-  for (int q = 0; q < C::NP2; ++q)
-#pragma unroll
-    for (int k = 0; k < C::R2; ++k)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, Own<C>::out_index(l, q, k, t))] = out[(q * C::R2 + k) * 4 + t];
+    for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
+  });
   if constexpr (POINTWISE) {
     const double tot = block_sum(s2, red);
     if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
@@ -111,36 +113,112 @@ __global__ __launch_bounds__(256, 2) void k_row_fwd(const typename C::T* __restr
 }
 
 // ---------------------------------------------------------------------------
-// k_row_inv: one group per row: T2 (tile-major) -> DCT-III -> U (row-major).
+// k_row_inv: one group per row: T2 (tile-major) -> DCT-III -> U (row-major, solver.py:208).
+//   DIAG: while U is in registers, the pointwise part of the record of this step
+//         (solver.py:218-228): bulk energy density, |U - mean| and the U < threshold
+//         count, plus the column-edge terms of the gradient energy (the rest of E2
+//         comes from the spectrum, see k_col).  partDiag[block] = {sE, sEdge, sPS, cSA}.
+//   FUSE: the row then goes straight on to the next timestep: EnergieEut (solver.py:
+//         166-175, sharing log U and log(1-U) with the energy density), sum(mu^2), and
+//         the forward row DCT-II into T1 -- U is never re-read from HBM.
 // ---------------------------------------------------------------------------
-template <class C>
-__global__ __launch_bounds__(256, 2) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
-                                                 FTables<typename C::T> tb, const DevState* __restrict__ st) {
+#ifndef CHS_LB_FUSED
+#define CHS_LB_FUSED 2
+#endif
+#ifndef CHS_LB_COL
+#define CHS_LB_COL 2
+#endif
+template <class C, bool DIAG, bool FUSE>
+__global__ __launch_bounds__(256, (DIAG && FUSE) ? CHS_LB_FUSED : 2) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
+                                                    typename C::T* __restrict__ T1, FTables<typename C::T> tb,
+                                                    DevConsts dc, const DevState* __restrict__ st,
+                                                    double* __restrict__ partDiag, double* __restrict__ partMu) {
   using T = typename C::T;
+  __shared__ double red[32];
+  static_assert(C::THREADS == 256, "block_sum_store assumes 4 waves");
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
   const int row = blockIdx.x * C::C + sub;
   T* scr = lds + (size_t)sub * C::SCR;
-  T out[2 * C::E];
-#pragma unroll
-  for (int q = 0; q < C::NP2; ++q)
-#pragma unroll
-    for (int k = 0; k < C::R2; ++k)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) out[(q * C::R2 + k) * 4 + t] = T2[tile_addr<C>(row, Own<C>::out_index(l, q, k, t))];
   T re[C::E], im[C::E];
-  inv_transform<C>(out, re, im, scr, tb, l);
+  recombine<C, false, true>(re, im, tb, l, [&](int, const int idx[4], T y[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y[t] = T2[tile_addr<C>(row, idx[t])];
+  });
+  inv_passes<C>(re, im, scr, tb, launder(l));
+  __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
   T* urow = U + (size_t)row * C::N;
+  double sEdge = 0.0;
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const int ls = launder(l);
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
-    const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
+    const int m1 = ls + C::G * q, m2 = C::L1 - 1 - m1;
 #pragma unroll
     for (int j = 0; j < C::R0 / 2; ++j) {
       T q1[4], q2[4];
       unpack_quads<C>(re, im, q, j, q1, q2);
       store4<T>(urow + 4 * (size_t)(m1 + C::L1 * j), q1);
       store4<T>(urow + 4 * (size_t)(m2 + C::L1 * j), q2);
+      if constexpr (DIAG) {
+        // np.gradient edge columns: (U[r,1]-U[r,0]) and (U[r,N-1]-U[r,N-2]) live in lane 0
+        if (q == 0 && j == 0 && m1 == 0) {
+          const double d = (double)q1[1] - (double)q1[0];
+          sEdge += d * d;
+        }
+        if (q == 0 && j == C::R0 / 2 - 1 && m1 == 0) {
+          const double d = (double)q2[3] - (double)q2[2];
+          sEdge += d * d;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (DIAG) {
+    const T RT = (T)dc.RT, BRT = (T)dc.BRT, B = (T)dc.B, A0 = (T)dc.A0, A1 = (T)dc.A1;
+    const double mean = st->meanU, thr = dc.threshold;
+    double sE = 0.0, sPS = 0.0, cSA = 0.0, s2 = 0.0;
+    auto point = [&](T& u) {
+      const T uinv = T(1) - u;
+      const T lU = chs_log<T>(u), lV = chs_log<T>(uinv);
+      sE += (double)chs_energy_from_logs<T>(u, uinv, lU, lV, RT, B, A0, A1);
+      sPS += fabs((double)u - mean);
+      cSA += ((double)u < thr) ? 1.0 : 0.0;
+      if constexpr (FUSE) {
+        const T m = chs_mu_from_logs<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
+        s2 += (double)m * (double)m;
+        u = m;
+        // opaque use: finishes this grid point before the next one starts, so the
+        // intermediates (logs, 1-U, ...) of 128 points are never alive together
+        asm volatile("" : "+v"(u));
+      }
+    };
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) {
+      point(re[e]);
+      point(im[e]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    acc[0] = sE; acc[1] = sEdge; acc[2] = sPS; acc[3] = cSA; acc[4] = s2;
+  }
+  if constexpr (FUSE) {
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_passes<C>(re, im, scr, tb, launder(l));
+    __builtin_amdgcn_sched_barrier(0);
+    recombine<C, true, false>(re, im, tb, launder(l), [&](int, const int idx[4], T y[4]) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
+    });
+  }
+  if constexpr (DIAG) {
+    // reductions last: the transform registers are dead by now
+    double out5[5];
+    block_sum_store<5>(acc, red, out5);
+    if (threadIdx.x == 0) {
+      double* p = partDiag + (size_t)blockIdx.x * 4;
+      p[0] = out5[0]; p[1] = out5[1]; p[2] = out5[2]; p[3] = out5[3];
+      if (FUSE) partMu[blockIdx.x] = out5[4];
     }
   }
 }
@@ -149,6 +227,9 @@ __global__ __launch_bounds__(256, 2) void k_row_inv(const typename C::T* __restr
 // k_col: one workgroup per column tile (C columns, one group each).
 // The tile (N rows x C columns, contiguous) is staged through LDS in two rounds of
 // N/2 rows so that HBM sees only 16-byte coalesced accesses.
+// MODE_STEP also accumulates sum(hat_U^2 (sin^2(pi kr/N) + sin^2(pi kc/N))) per tile:
+// by Parseval this is the interior part of np.gradient's sum of squares (solver.py:
+// 213-217) -- see DESIGN.md section "E2 from the spectrum".
 // ---------------------------------------------------------------------------
 template <class C>
 struct ColStage {
@@ -166,12 +247,14 @@ constexpr int col_lds_elems() {
 }
 
 template <class C, int MODE>
-__global__ __launch_bounds__(256, 2) void k_col(const typename C::T* __restrict__ Tin, typename C::T* __restrict__ Tout,
-                                             typename C::T* __restrict__ hat, typename C::T* __restrict__ nat,
-                                             FTables<typename C::T> tb, const double* __restrict__ lam,
-                                             DevState* __restrict__ st) {
+__global__ __launch_bounds__(256, (MODE == MODE_STEP) ? CHS_LB_COL : 2) void k_col(const typename C::T* __restrict__ Tin, typename C::T* __restrict__ Tout,
+                                                typename C::T* __restrict__ hat, typename C::T* __restrict__ nat,
+                                                FTables<typename C::T> tb, const double* __restrict__ lam,
+                                                const double* __restrict__ sinsq, DevState* __restrict__ st,
+                                                double* __restrict__ partE2) {
   using T = typename C::T;
   using CS = ColStage<C>;
+  __shared__ double red[32];
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
@@ -179,7 +262,6 @@ __global__ __launch_bounds__(256, 2) void k_col(const typename C::T* __restrict_
   const int kc = ct * C::C + sub;  // this group's column
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
-  T out[2 * C::E];
 
   if constexpr (MODE != MODE_INV_NATURAL) {
     // ---- stage in: tile rows -> quads of this group's column
@@ -219,40 +301,44 @@ __global__ __launch_bounds__(256, 2) void k_col(const typename C::T* __restrict_
       }
     }
     __syncthreads();
-    fwd_transform<C>(re, im, out, scr, tb, l);
+    fwd_passes<C>(re, im, scr, tb, l);
   }
 
-  // ---- spectral stage on this lane's coefficients
+  // ---- recombination / spectral stage / adjoint recombination, in place per slot
   T* hcol = hat + (size_t)kc * C::N;
   const double lam1 = st->lam1, lam2 = st->lam2;
   const double lc = lam[kc];
+  const double sqc = (MODE == MODE_STEP) ? sinsq[kc] : 0.0;
+  double e2 = 0.0;
+  constexpr bool FWD = (MODE != MODE_INV_NATURAL);
+  constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL);
+  recombine<C, FWD, ADJ>(re, im, tb, l, [&](int pbase, const int idx[4], T y[4]) {
 #pragma unroll
-  for (int q = 0; q < C::NP2; ++q)
-#pragma unroll
-    for (int k = 0; k < C::R2; ++k)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int p = (q * C::R2 + k) * 4 + t;
-        const int kr = Own<C>::out_index(l, q, k, t);
-        if constexpr (MODE == MODE_STEP) {
-          const T h = chs_spectral<T>(hcol[(size_t)p * C::G + l], out[p], lam[kr], lc, lam1, lam2);
-          hcol[(size_t)p * C::G + l] = h;
-          out[p] = h;
-          if (kr == 0 && kc == 0) st->meanU = (double)h / (double)C::N;
-        } else if constexpr (MODE == MODE_FWD_NATIVE) {
-          hcol[(size_t)p * C::G + l] = out[p];
-        } else if constexpr (MODE == MODE_FWD_NATURAL) {
-          nat[(size_t)kr * C::N + kc] = out[p];
-        } else {
-          out[p] = nat[(size_t)kr * C::N + kc];
-        }
-        if constexpr (MODE == MODE_STEP) {
-          if (t == 3 && (k & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight
-        }
+    for (int t = 0; t < 4; ++t) {
+      const int kr = idx[t];
+      const size_t hp = (size_t)(pbase + t) * C::G + l;
+      if constexpr (MODE == MODE_STEP) {
+        const T h = chs_spectral<T>(hcol[hp], y[t], lam[kr], lc, lam1, lam2);
+        hcol[hp] = h;
+        y[t] = h;
+        e2 += (double)h * (double)h * (sinsq[kr] + sqc);
+        if (kr == 0 && kc == 0) st->meanU = (double)h / (double)C::N;  // ortho DC term = sum(U)/N
+      } else if constexpr (MODE == MODE_FWD_NATIVE) {
+        hcol[hp] = y[t];
+      } else if constexpr (MODE == MODE_FWD_NATURAL) {
+        nat[(size_t)kr * C::N + kc] = y[t];
+      } else {
+        y[t] = nat[(size_t)kr * C::N + kc];
       }
+    }
+  });
+  if constexpr (MODE == MODE_STEP) {
+    const double tot = block_sum(e2, red);
+    if (threadIdx.x == 0) partE2[ct] = tot;
+  }
 
-  if constexpr (MODE == MODE_STEP || MODE == MODE_INV_NATURAL) {
-    inv_transform<C>(out, re, im, scr, tb, l);
+  if constexpr (ADJ) {
+    inv_passes<C>(re, im, scr, tb, l);
     // ---- stage out: quads -> tile rows
     T* tile = Tout + (size_t)ct * C::N * C::C;
 #pragma unroll
@@ -288,12 +374,14 @@ __global__ __launch_bounds__(256, 2) void k_col(const typename C::T* __restrict_
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+enum { ROW_INV_PLAIN = 0, ROW_INV_DIAG = 1, ROW_INV_FUSED = 2 };
+
 struct FastPlan {
   int N, G, R0, R1, R2;
   void* tables = nullptr;  // one device allocation
   size_t off_tw0, off_tw1, off_wp, off_t1, off_t2;  // element offsets
   int (*row_fwd)(Engine*, const void*, void*, bool) = nullptr;
-  int (*row_inv)(Engine*, const void*, void*) = nullptr;
+  int (*row_inv)(Engine*, int, const void*, void*, void*) = nullptr;
   int (*col)(Engine*, int, const void*, void*, void*, void*) = nullptr;
   int (*init)(Engine*) = nullptr;
 };
@@ -314,15 +402,23 @@ struct Launch {
   static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T);
   static constexpr size_t col_lds = (size_t)col_lds_elems<C>() * sizeof(T);
 
+  template <class K>
+  static int set_lds(K kernel, size_t bytes) {
+    CHS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return CHS_OK;
+  }
   static int init(Engine* E) {
     (void)E;
-    CHS_HIP(hipFuncSetAttribute((const void*)k_row_fwd<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds));
-    CHS_HIP(hipFuncSetAttribute((const void*)k_row_fwd<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds));
-    CHS_HIP(hipFuncSetAttribute((const void*)k_row_inv<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds));
-    CHS_HIP(hipFuncSetAttribute((const void*)k_col<C, MODE_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds));
-    CHS_HIP(hipFuncSetAttribute((const void*)k_col<C, MODE_FWD_NATIVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds));
-    CHS_HIP(hipFuncSetAttribute((const void*)k_col<C, MODE_FWD_NATURAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds));
-    CHS_HIP(hipFuncSetAttribute((const void*)k_col<C, MODE_INV_NATURAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds));
+    int rc;
+    if ((rc = set_lds(k_row_fwd<C, true>, row_lds))) return rc;
+    if ((rc = set_lds(k_row_fwd<C, false>, row_lds))) return rc;
+    if ((rc = set_lds(k_row_inv<C, false, false>, row_lds))) return rc;
+    if ((rc = set_lds(k_row_inv<C, true, false>, row_lds))) return rc;
+    if ((rc = set_lds(k_row_inv<C, true, true>, row_lds))) return rc;
+    if ((rc = set_lds(k_col<C, MODE_STEP>, col_lds))) return rc;
+    if ((rc = set_lds(k_col<C, MODE_FWD_NATIVE>, col_lds))) return rc;
+    if ((rc = set_lds(k_col<C, MODE_FWD_NATURAL>, col_lds))) return rc;
+    if ((rc = set_lds(k_col<C, MODE_INV_NATURAL>, col_lds))) return rc;
     return CHS_OK;
   }
   static int row_fwd(Engine* E, const void* in, void* out, bool pointwise) {
@@ -336,9 +432,18 @@ struct Launch {
     CHS_HIP(hipGetLastError());
     return CHS_OK;
   }
-  static int row_inv(Engine* E, const void* in, void* out) {
+  static int row_inv(Engine* E, int mode, const void* t2, void* u, void* t1) {
     const int grid = C::N / C::C;
-    k_row_inv<C><<<grid, 256, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dState);
+    const FTables<T> tb = get_tables<T>(E);
+    if (mode == ROW_INV_PLAIN)
+      k_row_inv<C, false, false><<<grid, 256, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
+                                                                    E->dPartDiag, E->dPartMu);
+    else if (mode == ROW_INV_DIAG)
+      k_row_inv<C, true, false><<<grid, 256, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
+                                                                   E->dPartDiag, E->dPartMu);
+    else
+      k_row_inv<C, true, true><<<grid, 256, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
+                                                                  E->dPartDiag, E->dPartMu);
     CHS_HIP(hipGetLastError());
     return CHS_OK;
   }
@@ -347,16 +452,16 @@ struct Launch {
     const FTables<T> tb = get_tables<T>(E);
     switch (mode) {
       case MODE_STEP:
-        k_col<C, MODE_STEP><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dState);
+        k_col<C, MODE_STEP><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       case MODE_FWD_NATIVE:
-        k_col<C, MODE_FWD_NATIVE><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dState);
+        k_col<C, MODE_FWD_NATIVE><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       case MODE_FWD_NATURAL:
-        k_col<C, MODE_FWD_NATURAL><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dState);
+        k_col<C, MODE_FWD_NATURAL><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       default:
-        k_col<C, MODE_INV_NATURAL><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dState);
+        k_col<C, MODE_INV_NATURAL><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
     }
     CHS_HIP(hipGetLastError());
@@ -387,7 +492,7 @@ bool chs_fast_supported(int N, int dtype) {
 }
 
 static void twiddle(long double num, long double den, long double& c, long double& s) {
-  // exp(-2 pi i num/den) = c - i s, argument reduced exactly
+  // exp(-2 pi i num/den) = c - i s
   static const long double PI = 3.14159265358979323846264338327950288419716939937510L;
   const long double a = 2.0L * PI * (num / den);
   c = cosl(a); s = sinl(a);
@@ -429,7 +534,11 @@ static int build_tables(Engine* E, FastPlan* P) {
   for (int kk = 0; kk <= M; ++kk) { long double r, i; Tk(M - kk, r, i); push(r, -i); }
   CHS_HIP(hipMalloc(&P->tables, h.size() * sizeof(T)));
   CHS_HIP(hipMemcpy(P->tables, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-  (void)E;
+  // sin^2(pi k/N): weights of the spectral form of np.gradient's sum of squares
+  std::vector<double> sq(N);
+  for (int k = 0; k < N; ++k) { const long double v = sinl(PI * (long double)k / (long double)N); sq[k] = (double)(v * v); }
+  CHS_HIP(hipMalloc(&E->dSinSq, sizeof(double) * N));
+  CHS_HIP(hipMemcpy(E->dSinSq, sq.data(), sizeof(double) * N, hipMemcpyHostToDevice));
   return CHS_OK;
 }
 
@@ -448,8 +557,11 @@ int chs_fast_init(Engine* E) {
   int rc = build_tables<double>(E, P);
   if (rc) return rc;
   if ((rc = P->init(E))) return rc;
-  // k_row_fwd writes one sum(mu^2) partial per workgroup
-  E->nPartMu = E->N / (256 / P->G);
+  // the row kernels write one partial record per workgroup, k_col one per column tile
+  E->nRowBlocks = E->N / (256 / P->G);
+  E->nPartMu = E->nRowBlocks;
+  E->nPartE2 = E->nRowBlocks;
+  CHS_HIP(hipMalloc(&E->dPartE2, sizeof(double) * (size_t)E->nPartE2));
   return CHS_OK;
 }
 
@@ -457,6 +569,9 @@ void chs_fast_free(Engine* E) {
   FastPlan* P = (FastPlan*)E->dTw;
   if (!P) return;
   if (P->tables) hipFree(P->tables);
+  if (E->dSinSq) hipFree(E->dSinSq);
+  if (E->dPartE2) hipFree(E->dPartE2);
+  E->dSinSq = nullptr; E->dPartE2 = nullptr;
   delete P;
   E->dTw = nullptr;
 }
@@ -469,9 +584,10 @@ int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse) {
     return P->col(E, MODE_FWD_NATURAL, E->dT1, nullptr, E->dHat, out);
   }
   if ((rc = P->col(E, MODE_INV_NATURAL, nullptr, E->dT1, E->dHat, (void*)in))) return rc;
-  return P->row_inv(E, E->dT1, out);
+  return P->row_inv(E, ROW_INV_PLAIN, E->dT1, out, nullptr);
 }
 
+// hat_U <- dctn(U) in k_col's native order (solver.py:159)
 int chs_fast_enter(Engine* E) {
   FastPlan* P = (FastPlan*)E->dTw;
   int rc;
@@ -479,24 +595,54 @@ int chs_fast_enter(Engine* E) {
   return P->col(E, MODE_FWD_NATIVE, E->dT1, nullptr, E->dHat, nullptr);
 }
 
-int chs_fast_step(Engine* E) {
+// T1 <- row DCT-II of EnergieEut(U): what the fused row kernel of the previous step would
+// have left behind; needed once per solve_or_resume call.
+int chs_fast_prologue(Engine* E) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  chs_slot_begin(E, SLOT_MU);
+  const int rc = P->row_fwd(E, E->dU, E->dT1, true);
+  chs_slot_end(E, SLOT_MU);
+  return rc;
+}
+
+// One timestep on the fused pipeline.  On entry T1 holds the row transform of
+// EnergieEut(U_k) and partMu its sum of squares; on exit U_(k+1) is in HBM, the pointwise
+// diagnostics partials of U_(k+1) are ready for k_fin and, with fuse_next, T1/partMu are
+// ready for the next step.
+int chs_fast_step(Engine* E, bool fuse_next) {
   FastPlan* P = (FastPlan*)E->dTw;
   int rc;
   if (E->dc.adaptive_time) {
     // column sums of the adaptive-step integrand (solver.py:183) on the steps that need them
     if ((rc = chs_launch_mu_colsums(E))) return rc;
   }
-  chs_slot_begin(E, SLOT_MU);
-  rc = P->row_fwd(E, E->dU, E->dT1, true);
-  chs_slot_end(E, SLOT_MU);
-  if (rc) return rc;
   if ((rc = chs_launch_pre(E))) return rc;
   chs_slot_begin(E, SLOT_SPEC);
   rc = P->col(E, MODE_STEP, E->dT1, E->dT2, E->dHat, nullptr);
   chs_slot_end(E, SLOT_SPEC);
   if (rc) return rc;
   chs_slot_begin(E, SLOT_INV);
-  rc = P->row_inv(E, E->dT2, E->dU);
+  rc = P->row_inv(E, fuse_next ? ROW_INV_FUSED : ROW_INV_DIAG, E->dT2, E->dU, E->dT1);
+  chs_slot_end(E, SLOT_INV);
+  return rc;
+}
+
+// Jitter path (solver.py:210-211 perturbs U between the inverse transform and the record):
+// no fusion across the perturbation; the caller adds noise, k_sum, k_diag, k_fin.
+int chs_fast_step_unfused(Engine* E) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  int rc;
+  if ((rc = chs_fast_prologue(E))) return rc;
+  if (E->dc.adaptive_time) {
+    if ((rc = chs_launch_mu_colsums(E))) return rc;
+  }
+  if ((rc = chs_launch_pre(E))) return rc;
+  chs_slot_begin(E, SLOT_SPEC);
+  rc = P->col(E, MODE_STEP, E->dT1, E->dT2, E->dHat, nullptr);
+  chs_slot_end(E, SLOT_SPEC);
+  if (rc) return rc;
+  chs_slot_begin(E, SLOT_INV);
+  rc = P->row_inv(E, ROW_INV_PLAIN, E->dT2, E->dU, nullptr);
   chs_slot_end(E, SLOT_INV);
   return rc;
 }

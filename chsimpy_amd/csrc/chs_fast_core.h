@@ -278,12 +278,12 @@ __device__ __forceinline__ void slot_adj(T y0, T y1, T y2, T y3, const FTables<T
 // ---------------------------------------------------------------------------
 
 // ===========================================================================
-// Forward transform.  In: re/im[E] = pass-0 operands, index ((q*2+b)*R0 + j).
-// Out: out[2E] reals, index ((q*R2 + k)*4 + t)  (see Own::out_index).
+// Forward radix passes.  In: re/im[E] = pass-0 operands, index ((q*2+b)*R0 + j).
+// Out: re/im[E] = last-pass outputs Z, index ((q*2+b)*R2 + k)  (b = 0: kappa1, 1: kappa2).
 // ===========================================================================
 template <class C>
-__device__ __forceinline__ void fwd_transform(typename C::T* re, typename C::T* im, typename C::T* out,
-                                              typename C::T* scr, const FTables<typename C::T>& tb, int l) {
+__device__ __forceinline__ void fwd_passes(typename C::T* re, typename C::T* im, typename C::T* scr,
+                                           const FTables<typename C::T>& tb, int l) {
   using T = typename C::T;
   constexpr int R0 = C::R0, R1 = C::R1, R2 = C::R2;
   // ---- pass 0: radix R0 on every owned butterfly, then twiddle by omega_M^(m k0)
@@ -386,84 +386,95 @@ __device__ __forceinline__ void fwd_transform(typename C::T* re, typename C::T* 
       }
     }
   }
-  // ---- last pass + recombination
+  // ---- last pass
+#pragma unroll
+  for (int q = 0; q < 2 * C::NP2; ++q) Dft<T, R2, false>::run(re + q * R2, im + q * R2);
+}
+
+// ===========================================================================
+// Recombination stage, in place on the last-pass registers.
+//   FWD: (A, Z) -> y[4] = the four real coefficients of the slot (slot_fwd)
+//   f(pbase, idx, y): the caller consumes / replaces y.  pbase = (q*R2 + k)*4 is the
+//        compile-time position of the slot, idx[t] the coefficient index of y[t]
+//        (Own::out_index).
+//   ADJ: y[4] -> (gA, gZ) written back over (A, Z) (slot_adj)
+// With FWD only the registers are left untouched; with ADJ only y comes from f.
+// ===========================================================================
+template <class C, bool FWD, bool ADJ, class F>
+__device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, const FTables<typename C::T>& tb,
+                                          int l, F&& f) {
+  using T = typename C::T;
+  constexpr int R2 = C::R2, N = C::N, M = C::M;
 #pragma unroll
   for (int q = 0; q < C::NP2; ++q) {
     int k1, k2; bool sp;
     Own<C>::last_pair(l, q, k1, k2, sp);
     T* r1 = re + (q * 2 + 0) * R2; T* i1 = im + (q * 2 + 0) * R2;
     T* r2 = re + (q * 2 + 1) * R2; T* i2 = im + (q * 2 + 1) * R2;
-    Dft<T, R2, false>::run(r1, i1);
-    Dft<T, R2, false>::run(r2, i2);
-    T* o = out + q * R2 * 4;
     if (!sp) {
 #pragma unroll
-      for (int k = 0; k < R2; ++k)
-        slot_fwd<T>(r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k], tb, k1 + C::S2 * k, o[k * 4 + 0], o[k * 4 + 1],
-                    o[k * 4 + 2], o[k * 4 + 3]);
+      for (int k = 0; k < R2; ++k) {
+        const int kk = k1 + C::S2 * k;
+        T y[4] = {T(0), T(0), T(0), T(0)};
+        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k], tb, kk, y[0], y[1], y[2], y[3]);
+        const int idx[4] = {kk, N - kk, M - kk, M + kk};
+        f((q * R2 + k) * 4, idx, y);
+        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], tb, kk, r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
+      }
     } else {
-      // butterfly 0 pairs with itself (k <-> R2-k), butterfly S2/2 with itself (k <-> R2-1-k)
-      T a0, a1, a2, a3, b0, b1, b2, b3;
-      slot_fwd<T>(r1[0], i1[0], r1[0], i1[0], tb, 0, a0, a1, a2, a3);                              // kk = 0
-      slot_fwd<T>(r1[R2 / 2], i1[R2 / 2], r1[R2 / 2], i1[R2 / 2], tb, C::M / 2, b0, b1, b2, b3);    // kk = M/2
-      o[0] = a0; o[1] = b0; o[2] = a2; o[3] = b1;  // X[0], X[M/2], X[M], X[3M/2]
+      // butterfly 0 pairs with itself (k <-> R2-k), butterfly S2/2 with itself (k <-> R2-1-k);
+      // position 0 holds (X[0], X[M/2], X[M], X[3M/2]) from the two self-paired outputs
+      {
+        T y[4] = {T(0), T(0), T(0), T(0)};
+        if constexpr (FWD) {
+          T a0, a1, a2, a3, b0, b1, b2, b3;
+          slot_fwd<T>(r1[0], i1[0], r1[0], i1[0], tb, 0, a0, a1, a2, a3);
+          slot_fwd<T>(r1[R2 / 2], i1[R2 / 2], r1[R2 / 2], i1[R2 / 2], tb, M / 2, b0, b1, b2, b3);
+          y[0] = a0; y[1] = b0; y[2] = a2; y[3] = b1;
+        }
+        const int idx[4] = {0, M / 2, M, 3 * (M / 2)};
+        f(q * R2 * 4, idx, y);
+        if constexpr (ADJ) {
+          T gar, gai, gzr, gzi;
+          slot_adj<T>(y[0], T(0), y[2], T(0), tb, 0, gar, gai, gzr, gzi);
+          r1[0] = gar + gzr; i1[0] = gai + gzi;
+          slot_adj<T>(y[1], y[3], T(0), T(0), tb, M / 2, gar, gai, gzr, gzi);
+          r1[R2 / 2] = gar + gzr; i1[R2 / 2] = gai + gzi;
+        }
+      }
 #pragma unroll
-      for (int k = 1; k < R2 / 2; ++k)
-        slot_fwd<T>(r1[k], i1[k], r1[R2 - k], i1[R2 - k], tb, C::S2 * k, o[k * 4 + 0], o[k * 4 + 1], o[k * 4 + 2],
-                    o[k * 4 + 3]);
+      for (int k = 1; k < R2 / 2; ++k) {
+        const int kk = C::S2 * k;
+        T y[4] = {T(0), T(0), T(0), T(0)};
+        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r1[R2 - k], i1[R2 - k], tb, kk, y[0], y[1], y[2], y[3]);
+        const int idx[4] = {kk, N - kk, M - kk, M + kk};
+        f((q * R2 + k) * 4, idx, y);
+        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], tb, kk, r1[k], i1[k], r1[R2 - k], i1[R2 - k]);
+      }
 #pragma unroll
-      for (int k = 0; k < R2 / 2; ++k)
-        slot_fwd<T>(r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k], tb, C::S2 / 2 + C::S2 * k,
-                    o[(R2 / 2 + k) * 4 + 0], o[(R2 / 2 + k) * 4 + 1], o[(R2 / 2 + k) * 4 + 2],
-                    o[(R2 / 2 + k) * 4 + 3]);
+      for (int k = 0; k < R2 / 2; ++k) {
+        const int kk = C::S2 / 2 + C::S2 * k;
+        T y[4] = {T(0), T(0), T(0), T(0)};
+        if constexpr (FWD) slot_fwd<T>(r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k], tb, kk, y[0], y[1], y[2], y[3]);
+        const int idx[4] = {kk, N - kk, M - kk, M + kk};
+        f((q * R2 + R2 / 2 + k) * 4, idx, y);
+        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], tb, kk, r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
+      }
     }
   }
 }
 
 // ===========================================================================
-// Inverse transform (exact transpose).  In: out[2E] positions as above.
-// Out: re/im[E] = pass-0 operand gradients, index ((q*2+b)*R0 + j) (to be unpacked
-// into quads by the caller).
+// Inverse radix passes (exact transpose of fwd_passes).  In: re/im[E] = last-pass
+// output gradients, index ((q*2+b)*R2 + k).  Out: pass-0 operands ((q*2+b)*R0 + j).
 // ===========================================================================
 template <class C>
-__device__ __forceinline__ void inv_transform(const typename C::T* out, typename C::T* re, typename C::T* im,
-                                              typename C::T* scr, const FTables<typename C::T>& tb, int l) {
+__device__ __forceinline__ void inv_passes(typename C::T* re, typename C::T* im, typename C::T* scr,
+                                           const FTables<typename C::T>& tb, int l) {
   using T = typename C::T;
   constexpr int R0 = C::R0, R1 = C::R1, R2 = C::R2;
-  // ---- recombination adjoint + last pass (conjugate DFT)
 #pragma unroll
-  for (int q = 0; q < C::NP2; ++q) {
-    int k1, k2; bool sp;
-    Own<C>::last_pair(l, q, k1, k2, sp);
-    T* r1 = re + (q * 2 + 0) * R2; T* i1 = im + (q * 2 + 0) * R2;
-    T* r2 = re + (q * 2 + 1) * R2; T* i2 = im + (q * 2 + 1) * R2;
-    const T* o = out + q * R2 * 4;
-    if (!sp) {
-#pragma unroll
-      for (int k = 0; k < R2; ++k)
-        slot_adj<T>(o[k * 4 + 0], o[k * 4 + 1], o[k * 4 + 2], o[k * 4 + 3], tb, k1 + C::S2 * k, r1[k], i1[k],
-                    r2[R2 - 1 - k], i2[R2 - 1 - k]);
-    } else {
-      T gar, gai, gzr, gzi;
-      // kk = 0: y = (X[0], -, X[M], -); both operands are Z[0]
-      slot_adj<T>(o[0], T(0), o[2], T(0), tb, 0, gar, gai, gzr, gzi);
-      r1[0] = gar + gzr; i1[0] = gai + gzi;
-      // kk = M/2: y = (X[M/2], X[3M/2], -, -); both operands are Z[M/2]
-      slot_adj<T>(o[1], o[3], T(0), T(0), tb, C::M / 2, gar, gai, gzr, gzi);
-      r1[R2 / 2] = gar + gzr; i1[R2 / 2] = gai + gzi;
-#pragma unroll
-      for (int k = 1; k < R2 / 2; ++k)
-        slot_adj<T>(o[k * 4 + 0], o[k * 4 + 1], o[k * 4 + 2], o[k * 4 + 3], tb, C::S2 * k, r1[k], i1[k], r1[R2 - k],
-                    i1[R2 - k]);
-#pragma unroll
-      for (int k = 0; k < R2 / 2; ++k)
-        slot_adj<T>(o[(R2 / 2 + k) * 4 + 0], o[(R2 / 2 + k) * 4 + 1], o[(R2 / 2 + k) * 4 + 2],
-                    o[(R2 / 2 + k) * 4 + 3], tb, C::S2 / 2 + C::S2 * k, r2[k], i2[k], r2[R2 - 1 - k],
-                    i2[R2 - 1 - k]);
-    }
-    Dft<T, R2, true>::run(r1, i1);
-    Dft<T, R2, true>::run(r2, i2);
-  }
+  for (int q = 0; q < 2 * C::NP2; ++q) Dft<T, R2, true>::run(re + q * R2, im + q * R2);
   // ---- exchange A2[m''][kappa] back
   T xr[C::E], xi[C::E];
 #pragma unroll

@@ -57,7 +57,11 @@ __device__ __forceinline__ double chs_log_f64(double x) {
   const double lq = chs_log_poly(s);
   const double k = (double)e;
   double res = __builtin_fma(k, CHS_LN2_HI, __builtin_fma(k, CHS_LN2_LO, lq));
-  res = (x > 0.0) ? res : ((x == 0.0) ? -__builtin_inf() : __builtin_nan(""));
+  // The opaque asm pins the computation above this point: without it the compiler turns the
+  // selects below into divergent branches around the whole routine.
+  asm volatile("" : "+v"(res));
+  const double bad = (x == 0.0) ? -__builtin_inf() : __builtin_nan("");
+  res = (x > 0.0) ? res : bad;
   res = (x == __builtin_inf()) ? x : res;
   return res;
 }
@@ -77,6 +81,7 @@ __device__ __forceinline__ double chs_log_ratio_f64(double a, double b) {
   double res = __builtin_fma(k, CHS_LN2_HI, __builtin_fma(k, CHS_LN2_LO, lq));
   // numpy gives NaN / -inf / +inf for a quotient that is negative / 0 / x/0; all of them
   // poison the step and trip the reference's NaN assertion, so one NaN covers them
+  asm volatile("" : "+v"(res));  // keep the selects below as selects (see chs_log_f64)
   const bool ok = (a > 0.0) && (b > 0.0) && (a < __builtin_inf()) && (b < __builtin_inf());
   return ok ? res : __builtin_nan("");  // every non-finite case ends in the NaN assertion anyway
 }
@@ -114,6 +119,27 @@ __device__ __forceinline__ T chs_energy_density(T U, T RT, T B, T A0, T A1) {
   const T b = Uinv * chs_log<T>(Uinv);
   const T c = ((A0 + A1 * (Uinv - U)) * U) * Uinv;
   return RT * (a + b) + c;
+}
+
+// The same two expressions with log(U) and log(1-U) supplied by the caller, so that the
+// fused row kernel evaluates two logarithms per grid point instead of three
+// (log(U/(1-U)) = log U - log(1-U)).
+template <typename T>
+__device__ __forceinline__ T chs_energy_from_logs(T U, T Uinv, T lU, T lV, T RT, T B, T A0, T A1) {
+#pragma clang fp contract(off)
+  const T a = U * (lU - B);
+  const T b = Uinv * lV;
+  const T c = ((A0 + A1 * (Uinv - U)) * U) * Uinv;
+  return RT * (a + b) + c;
+}
+template <typename T>
+__device__ __forceinline__ T chs_mu_from_logs(T U, T Uinv, T lU, T lV, T RT, T BRT, T A0, T A1) {
+#pragma clang fp contract(off)
+  const T U2inv = Uinv - U;
+  const T t1 = RT * (lU - lV);
+  const T t2 = (A0 + A1 * U2inv) * U2inv;
+  const T t3 = ((T(2) * A1) * U) * Uinv;
+  return ((t1 - BRT) + t2) - t3;
 }
 
 // Adaptive-step integrand, chsimpy/solver.py:182-183:

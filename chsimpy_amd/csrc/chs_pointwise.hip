@@ -221,7 +221,8 @@ __global__ __launch_bounds__(PW_THREADS) void k_diag(const T* __restrict__ U, De
 template <typename T>
 __global__ __launch_bounds__(PW_THREADS) void k_fin(const T* __restrict__ U, DevConsts dc, DevState* __restrict__ st,
                                                     const double* __restrict__ partDiag, int nPart,
-                                                    double* __restrict__ rows, long long rowsCap, int prepare_mode) {
+                                                    double* __restrict__ rows, long long rowsCap, int prepare_mode,
+                                                    const double* __restrict__ partE2, int nE2, int fused) {
   __shared__ double scratch[32];
   if (!prepare_mode && st->halt) return;
   const int N = dc.N;
@@ -236,6 +237,23 @@ __global__ __launch_bounds__(PW_THREADS) void k_fin(const T* __restrict__ U, Dev
   sG = block_sum(sG, scratch);
   sP = block_sum(sP, scratch);
   sS = block_sum(sS, scratch);
+  if (fused) {
+    // Fused fast-engine record: sG so far holds the column-edge terms.  np.gradient's sum of
+    // squares = [4 * sum(hat_U^2 (sin^2(pi kr/N) + sin^2(pi kc/N))) + 3 * (edge terms)] / (4 delx^2):
+    // central differences of the even-extended field are diagonal in the DCT-II basis, and the
+    // one-sided edge rows/columns are twice the extended central ones (4x^2 = x^2 + 3x^2).
+    double sp = 0.0;
+    for (int i = threadIdx.x; i < nE2; i += PW_THREADS) sp += partE2[i];
+    sp = block_sum(sp, scratch);
+    double er = 0.0;
+    for (int c = threadIdx.x; c < N; c += PW_THREADS) {
+      const double d0 = (double)U[(size_t)N + c] - (double)U[c];
+      const double d1 = (double)U[(size_t)(N - 1) * N + c] - (double)U[(size_t)(N - 2) * N + c];
+      er += d0 * d0 + d1 * d1;
+    }
+    er = block_sum(er, scratch);
+    sG = (4.0 * sp + 3.0 * (sG + er)) / (4.0 * dc.delx * dc.delx);
+  }
   // Ra: solver.py:226-227 (row int(N/2)+1; two passes over one row)
   const int rr = N / 2 + 1;
   double s = 0.0;
@@ -323,7 +341,7 @@ int chs_pointwise_alloc(Engine* E) {
   E->nColMinBlocks = (N + PW_THREADS - 1) / PW_THREADS;
   CHS_HIP(hipMalloc(&E->dPartMu, sizeof(double) * (size_t)(E->nBands > N ? E->nBands : N)));
   CHS_HIP(hipMalloc(&E->dPartMuAux, sizeof(double) * (size_t)E->nBands));
-  CHS_HIP(hipMalloc(&E->dPartDiag, sizeof(double) * 4 * (size_t)E->nDiagBlocks));
+  CHS_HIP(hipMalloc(&E->dPartDiag, sizeof(double) * 4 * (size_t)(E->nDiagBlocks > N ? E->nDiagBlocks : N)));
   CHS_HIP(hipMalloc(&E->dPartSum, sizeof(double) * (size_t)E->nBands));
   CHS_HIP(hipMalloc(&E->dPartColMin, sizeof(double) * (size_t)E->nColMinBlocks));
   CHS_HIP(hipMalloc(&E->dPartCol, sizeof(double) * (size_t)E->nBands * N));
@@ -411,13 +429,15 @@ int chs_launch_diag(Engine* E, int ignore_halt) {
   return CHS_OK;
 }
 
-int chs_launch_fin(Engine* E, int prepare_mode) {
+int chs_launch_fin(Engine* E, int prepare_mode, int fused) {
   chs_slot_begin(E, SLOT_FIN);
   DISPATCH_T(E,
     (k_fin<double><<<1, PW_THREADS, 0, E->stream>>>((const double*)E->dU, E->dc, E->dState, E->dPartDiag,
-                                                     E->nDiagBlocks, E->dRows, E->rowsCap, prepare_mode)),
+                                                     fused ? E->nRowBlocks : E->nDiagBlocks, E->dRows, E->rowsCap,
+                                                     prepare_mode, E->dPartE2, E->nPartE2, fused)),
     (k_fin<float><<<1, PW_THREADS, 0, E->stream>>>((const float*)E->dU, E->dc, E->dState, E->dPartDiag,
-                                                    E->nDiagBlocks, E->dRows, E->rowsCap, prepare_mode)));
+                                                    fused ? E->nRowBlocks : E->nDiagBlocks, E->dRows, E->rowsCap,
+                                                    prepare_mode, E->dPartE2, E->nPartE2, fused)));
   chs_slot_end(E, SLOT_FIN);
   CHS_HIP(hipGetLastError());
   return CHS_OK;
