@@ -83,11 +83,11 @@ __device__ __forceinline__ double block_min(double v, double* scratch) {
   return t;
 }
 
-// NV per-thread values -> block totals (256-thread blocks), written by thread 0 to out[0..NV).
+// NV per-thread values -> block totals (NW waves per block), left in out[0..NV) of thread 0.
 // One barrier, no loops with run-time trip counts: meant for the END of a register-heavy
 // kernel, where control flow around live register arrays would cost spills.
-template <int NV>
-__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* red /* >= 4*NV */,
+template <int NV, int NW>
+__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* red /* >= NW*NV */,
                                                 double* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double w[NV];
@@ -100,7 +100,12 @@ __device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* r
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) out[i] = ((red[i] + red[NV + i]) + red[2 * NV + i]) + red[3 * NV + i];
+    for (int i = 0; i < NV; ++i) {
+      double t = red[i];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) t += red[w * NV + i];
+      out[i] = t;
+    }
   }
 }
 

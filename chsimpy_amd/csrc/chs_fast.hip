@@ -68,7 +68,7 @@ __device__ __forceinline__ int launder(int x) {
 // (Prologue of a solve_or_resume call, and the unfused/jitter path.)
 // ---------------------------------------------------------------------------
 template <class C, bool POINTWISE>
-__global__ __launch_bounds__(256, 2) void k_row_fwd(const typename C::T* __restrict__ U, typename C::T* __restrict__ T1,
+__global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C::T* __restrict__ U, typename C::T* __restrict__ T1,
                                                     FTables<typename C::T> tb, DevConsts dc,
                                                     const DevState* __restrict__ st, double* __restrict__ partMu) {
   using T = typename C::T;
@@ -129,13 +129,12 @@ __global__ __launch_bounds__(256, 2) void k_row_fwd(const typename C::T* __restr
 #define CHS_LB_COL 2
 #endif
 template <class C, bool DIAG, bool FUSE>
-__global__ __launch_bounds__(256, (DIAG && FUSE) ? CHS_LB_FUSED : 2) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
+__global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
                                                     typename C::T* __restrict__ T1, FTables<typename C::T> tb,
                                                     DevConsts dc, const DevState* __restrict__ st,
                                                     double* __restrict__ partDiag, double* __restrict__ partMu) {
   using T = typename C::T;
-  __shared__ double red[32];
-  static_assert(C::THREADS == 256, "block_sum_store assumes 4 waves");
+  __shared__ double red[64];
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
@@ -191,8 +190,11 @@ __global__ __launch_bounds__(256, (DIAG && FUSE) ? CHS_LB_FUSED : 2) void k_row_
         u = m;
         // opaque use: finishes this grid point before the next one starts, so the
         // intermediates (logs, 1-U, ...) of 128 points are never alive together
-        asm volatile("" : "+v"(u));
+        asm volatile("" : "+v"(u), "+v"(s2));
       }
+      // ... and the running sums: otherwise the compiler postpones all 2E energy terms
+      // (keeping log U, log(1-U), 1-U of every point alive) to add them up at the end
+      asm volatile("" : "+v"(sE), "+v"(sPS), "+v"(cSA));
     };
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, (DIAG && FUSE) ? CHS_LB_FUSED : 2) void k_row_
   if constexpr (DIAG) {
     // reductions last: the transform registers are dead by now
     double out5[5];
-    block_sum_store<5>(acc, red, out5);
+    block_sum_store<5, C::THREADS / 64>(acc, red, out5);
     if (threadIdx.x == 0) {
       double* p = partDiag + (size_t)blockIdx.x * 4;
       p[0] = out5[0]; p[1] = out5[1]; p[2] = out5[2]; p[3] = out5[3];
@@ -247,7 +249,7 @@ constexpr int col_lds_elems() {
 }
 
 template <class C, int MODE>
-__global__ __launch_bounds__(256, (MODE == MODE_STEP) ? CHS_LB_COL : 2) void k_col(const typename C::T* __restrict__ Tin, typename C::T* __restrict__ Tout,
+__global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T* __restrict__ Tin, typename C::T* __restrict__ Tout,
                                                 typename C::T* __restrict__ hat, typename C::T* __restrict__ nat,
                                                 FTables<typename C::T> tb, const double* __restrict__ lam,
                                                 const double* __restrict__ sinsq, DevState* __restrict__ st,
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_STEP) ? CHS_LB_COL : 2) void k_c
     for (int rho = 0; rho < 2; ++rho) {
       __syncthreads();
       const T* src = tile + (size_t)rho * CS::LINES * CS::LINE;
-      for (int f = 2 * threadIdx.x; f < CS::LINES * CS::LINE; f += 2 * 256) {
+      for (int f = 2 * threadIdx.x; f < CS::LINES * CS::LINE; f += 2 * C::THREADS) {
         T a, b;
         if constexpr (sizeof(T) == 8) {
           const double2 v = *reinterpret_cast<const double2*>(src + f);
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_STEP) ? CHS_LB_COL : 2) void k_c
         y[t] = nat[(size_t)kr * C::N + kc];
       }
     }
+    if constexpr (MODE == MODE_STEP) asm volatile("" : "+v"(e2));  // do not postpone the 2E energy terms
   });
   if constexpr (MODE == MODE_STEP) {
     const double tot = block_sum(e2, red);
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_STEP) ? CHS_LB_COL : 2) void k_c
       }
       __syncthreads();
       T* dst = tile + (size_t)rho * CS::LINES * CS::LINE;
-      for (int f = 2 * threadIdx.x; f < CS::LINES * CS::LINE; f += 2 * 256) {
+      for (int f = 2 * threadIdx.x; f < CS::LINES * CS::LINE; f += 2 * C::THREADS) {
         const int line = f / CS::LINE, off = f % CS::LINE;
         const T a = lds[line * CS::LP + off], b = lds[line * CS::LP + off + 1];
         if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst + f) = make_double2(a, b);
@@ -377,9 +380,9 @@ __global__ __launch_bounds__(256, (MODE == MODE_STEP) ? CHS_LB_COL : 2) void k_c
 enum { ROW_INV_PLAIN = 0, ROW_INV_DIAG = 1, ROW_INV_FUSED = 2 };
 
 struct FastPlan {
-  int N, G, R0, R1, R2;
+  int N, G, R0, RA, RB, RL, threads;
   void* tables = nullptr;  // one device allocation
-  size_t off_tw0, off_tw1, off_wp, off_t1, off_t2;  // element offsets
+  size_t off_tw0, off_twa, off_twb, off_wp, off_t1, off_t2;  // element offsets
   int (*row_fwd)(Engine*, const void*, void*, bool) = nullptr;
   int (*row_inv)(Engine*, int, const void*, void*, void*) = nullptr;
   int (*col)(Engine*, int, const void*, void*, void*, void*) = nullptr;
@@ -391,7 +394,7 @@ static FTables<T> get_tables(Engine* E) {
   FastPlan* P = (FastPlan*)E->dTw;
   const T* base = (const T*)P->tables;
   FTables<T> tb;
-  tb.tw0 = base + P->off_tw0; tb.tw1 = base + P->off_tw1; tb.wp = base + P->off_wp;
+  tb.tw0 = base + P->off_tw0; tb.twa = base + P->off_twa; tb.twb = base + P->off_twb; tb.wp = base + P->off_wp;
   tb.t1 = base + P->off_t1; tb.t2 = base + P->off_t2;
   return tb;
 }
@@ -424,10 +427,10 @@ struct Launch {
   static int row_fwd(Engine* E, const void* in, void* out, bool pointwise) {
     const int grid = C::N / C::C;
     if (pointwise)
-      k_row_fwd<C, true><<<grid, 256, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
+      k_row_fwd<C, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
                                                             E->dPartMu);
     else
-      k_row_fwd<C, false><<<grid, 256, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
+      k_row_fwd<C, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
                                                              E->dPartMu);
     CHS_HIP(hipGetLastError());
     return CHS_OK;
@@ -436,13 +439,13 @@ struct Launch {
     const int grid = C::N / C::C;
     const FTables<T> tb = get_tables<T>(E);
     if (mode == ROW_INV_PLAIN)
-      k_row_inv<C, false, false><<<grid, 256, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
+      k_row_inv<C, false, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
                                                                     E->dPartDiag, E->dPartMu);
     else if (mode == ROW_INV_DIAG)
-      k_row_inv<C, true, false><<<grid, 256, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
+      k_row_inv<C, true, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
                                                                    E->dPartDiag, E->dPartMu);
     else
-      k_row_inv<C, true, true><<<grid, 256, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
+      k_row_inv<C, true, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
                                                                   E->dPartDiag, E->dPartMu);
     CHS_HIP(hipGetLastError());
     return CHS_OK;
@@ -452,16 +455,16 @@ struct Launch {
     const FTables<T> tb = get_tables<T>(E);
     switch (mode) {
       case MODE_STEP:
-        k_col<C, MODE_STEP><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<C, MODE_STEP><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       case MODE_FWD_NATIVE:
-        k_col<C, MODE_FWD_NATIVE><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<C, MODE_FWD_NATIVE><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       case MODE_FWD_NATURAL:
-        k_col<C, MODE_FWD_NATURAL><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<C, MODE_FWD_NATURAL><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       default:
-        k_col<C, MODE_INV_NATURAL><<<grid, 256, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<C, MODE_INV_NATURAL><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
     }
     CHS_HIP(hipGetLastError());
@@ -469,17 +472,18 @@ struct Launch {
   }
 };
 
-// fp64 configurations: N -> (G, R0, R1, R2, pad1, pad2)
-using F128 = FCfg<double, 128, 4, 8, 1, 8, 0, 1>;
-using F256 = FCfg<double, 256, 8, 8, 2, 8, 1, 1>;
-using F512 = FCfg<double, 512, 16, 8, 4, 8, 1, 1>;
-using F1024 = FCfg<double, 1024, 32, 8, 8, 8, 2, 8>;
-using F2048 = FCfg<double, 2048, 64, 8, 16, 8, 2, 8>;
-using F4096 = FCfg<double, 4096, 64, 16, 8, 16, 2, 16>;
+// fp64 configurations: <T, N, G, THREADS, R0, RA, RB, RL, pad1, pad2, padL, waves/SIMD>
+using F128 = FCfg<double, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
+using F256 = FCfg<double, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
+using F512 = FCfg<double, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
+using F1024 = FCfg<double, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
+using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
+// N = 4096: two wavefronts per transform, 16 complex values per lane, four radix passes
+using F4096 = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 4>;
 
 template <class C>
 static void bind(FastPlan* P) {
-  P->N = C::N; P->G = C::G; P->R0 = C::R0; P->R1 = C::R1; P->R2 = C::R2;
+  P->N = C::N; P->G = C::G; P->R0 = C::R0; P->RA = C::RA; P->RB = C::RB; P->RL = C::RL; P->threads = C::THREADS;
   P->row_fwd = &Launch<C>::row_fwd;
   P->row_inv = &Launch<C>::row_inv;
   P->col = &Launch<C>::col;
@@ -500,7 +504,7 @@ static void twiddle(long double num, long double den, long double& c, long doubl
 
 template <typename T>
 static int build_tables(Engine* E, FastPlan* P) {
-  const int N = P->N, M = N / 2, L1 = M / P->R0, L2 = L1 / P->R1;
+  const int N = P->N, M = N / 2, L1 = M / P->R0, L2 = L1 / P->RA, L3 = L2 / P->RB;
   std::vector<T> h;
   auto push = [&](long double r, long double i) { h.push_back((T)r); h.push_back((T)i); };
   P->off_tw0 = h.size();
@@ -510,13 +514,21 @@ static int build_tables(Engine* E, FastPlan* P) {
       twiddle((long double)(((long long)m * k) % M), (long double)M, c, s);
       push(c, -s);
     }
-  P->off_tw1 = h.size();
-  for (int k = 1; k < P->R1; ++k)
+  P->off_twa = h.size();
+  for (int k = 1; k < P->RA; ++k)
     for (int m = 0; m < L2; ++m) {
       long double c, s;
       twiddle((long double)(((long long)m * k) % L1), (long double)L1, c, s);
       push(c, -s);
     }
+  P->off_twb = h.size();
+  for (int k = 1; k < P->RB; ++k)
+    for (int m = 0; m < L3; ++m) {
+      long double c, s;
+      twiddle((long double)(((long long)m * k) % L2), (long double)L2, c, s);
+      push(c, -s);
+    }
+  push(0, 0);  // keep every table pointer inside the allocation even when a pass is absent
   static const long double PI = 3.14159265358979323846264338327950288419716939937510L;
   P->off_wp = h.size();
   for (int kk = 0; kk <= M; ++kk) {  // -i exp(-2 pi i kk/N) = -sin(th) - i cos(th)
@@ -558,7 +570,7 @@ int chs_fast_init(Engine* E) {
   if (rc) return rc;
   if ((rc = P->init(E))) return rc;
   // the row kernels write one partial record per workgroup, k_col one per column tile
-  E->nRowBlocks = E->N / (256 / P->G);
+  E->nRowBlocks = E->N / (P->threads / P->G);
   E->nPartMu = E->nRowBlocks;
   E->nPartE2 = E->nRowBlocks;
   CHS_HIP(hipMalloc(&E->dPartE2, sizeof(double) * (size_t)E->nPartE2));

@@ -21,39 +21,54 @@
 // ---------------------------------------------------------------------------
 // compile-time configuration
 // ---------------------------------------------------------------------------
-template <typename T_, int N_, int G_, int R0_, int R1_, int R2_, int PAD1_, int PAD2_>
+template <typename T_, int N_, int G_, int THREADS_, int R0_, int RA_, int RB_, int RL_, int PAD1_, int PAD2_,
+          int PADL_, int WPS_>
 struct FCfg {
   using T = T_;
   static constexpr int N = N_;
   static constexpr int M = N_ / 2;
-  static constexpr int G = G_;          // lanes per transform
+  static constexpr int G = G_;          // lanes per transform (a "group")
   static constexpr int E = M / G_;      // complex values per lane
-  static constexpr int R0 = R0_, R1 = R1_, R2 = R2_;  // R1 == 1: two passes only
-  static constexpr int L1 = M / R0_;    // sub-transform length after pass 0
-  static constexpr int L2 = L1 / R1_;   // == R2
-  static constexpr int S1 = R0_;
-  static constexpr int S2 = R0_ * R1_;  // number of last-pass butterflies
+  // radices: pass 0, up to two middle passes (1 = absent), last pass
+  static constexpr int R0 = R0_, RA = RA_, RB = RB_, RL = RL_;
+  static constexpr int R2 = RL_;        // alias used by the recombination stage
+  static constexpr int S1 = R0_;             // resolved frequency digits before pass A
+  static constexpr int S2A = R0_ * RA_;      // ... before pass B
+  static constexpr int SL = R0_ * RA_ * RB_; // number of last-pass butterflies
+  static constexpr int S2 = SL;              // alias used by the recombination stage
+  static constexpr int L1 = M / R0_;         // sub-transform length after pass 0
+  static constexpr int L2 = L1 / RA_;        // ... after pass A
+  static constexpr int L3 = L2 / RB_;        // ... after pass B  (== RL)
   static constexpr int NP0 = E / (2 * R0_);  // mirror pairs per lane, pass 0
-  static constexpr int NB1 = E / R1_;        // butterflies per lane, pass 1
-  static constexpr int NP2 = E / (2 * R2_);  // mirror pairs per lane, last pass
-  static constexpr int THREADS = 256;
-  static constexpr int C = THREADS / G_;     // transforms per workgroup
-  static constexpr int P1 = L1 + PAD1_;      // pitch of A1[k0][m']
-  static constexpr int P2 = S2 + PAD2_;      // pitch of A2[m''][kappa]
-  static constexpr int SCR1 = (R1_ > 1) ? R0_ * P1 : 0;
-  static constexpr int SCR2 = R2_ * P2;
-  static constexpr int SCR = (SCR1 > SCR2 ? SCR1 : SCR2);  // scratch elements per transform
-  static_assert(L2 == R2_, "radices must multiply to M");
-  static_assert(NP0 >= 1 && NP2 >= 1, "E must be >= 2*R0 and >= 2*R2");
-  static_assert(R1_ == 1 || NB1 >= 1, "E must be >= R1");
-  static_assert(G_ <= 64 && (64 % G_) == 0, "a group must not span wavefronts");
+  static constexpr int NBA = E / RA_;        // butterflies per lane, pass A
+  static constexpr int NBB = E / RB_;        // butterflies per lane, pass B
+  static constexpr int NP2 = E / (2 * RL_);  // mirror pairs per lane, last pass
+  static constexpr int THREADS = THREADS_;
+  static constexpr int C = THREADS_ / G_;    // transforms per workgroup
+  static constexpr int WPS = WPS_;           // waves per SIMD the kernels are compiled for
+  static constexpr int P1 = L1 + PAD1_;      // pitch of X1[kappa < S1][m < L1]
+  static constexpr int P2 = L2 + PAD2_;      // pitch of X2[kappa < S2A][m < L2]
+  static constexpr int PL = SL + PADL_;      // pitch of XL[m < RL][kappa < SL]
+  static constexpr int SCR1 = (RA_ > 1) ? S1 * P1 : 0;
+  static constexpr int SCR2 = (RB_ > 1) ? S2A * P2 : 0;
+  static constexpr int SCRL = RL_ * PL;
+  static constexpr int SCR = (SCR1 > SCR2 ? (SCR1 > SCRL ? SCR1 : SCRL) : (SCR2 > SCRL ? SCR2 : SCRL));
+  static constexpr bool WAVE_LOCAL = (G_ <= 64);  // a group inside one wavefront needs no s_barrier
+  static_assert(L3 == RL_, "radices must multiply to M");
+  static_assert(RA_ > 1 || RB_ == 1, "use RA before RB");
+  static_assert(NP0 >= 1 && NP2 >= 1, "E must be >= 2*R0 and >= 2*RL");
+  static_assert(RA_ == 1 || NBA >= 1, "E must be >= RA");
+  static_assert(RB_ == 1 || NBB >= 1, "E must be >= RB");
+  static_assert((G_ <= 64 && (64 % G_) == 0) || (G_ % 64) == 0, "group size");
+  static_assert(THREADS_ % G_ == 0 && THREADS_ % 64 == 0, "workgroup size");
 };
 
 // twiddle tables in global memory (complex interleaved: re, im)
 template <typename T>
 struct FTables {
-  const T* tw0;  // [(k0-1)*L1 + m'] = omega_M^(m' k0),   k0 = 1..R0-1
-  const T* tw1;  // [(k1-1)*L2 + m''] = omega_L1^(m'' k1), k1 = 1..R1-1
+  const T* tw0;  // [(k-1)*L1 + m] = omega_M^(m k),    k = 1..R0-1, m < L1
+  const T* twa;  // [(k-1)*L2 + m] = omega_L1^(m k),   k = 1..RA-1, m < L2
+  const T* twb;  // [(k-1)*L3 + m] = omega_L2^(m k),   k = 1..RB-1, m < L3
   const T* wp;   // [kk] = -i exp(-2 pi i kk / N),          kk = 0..M
   const T* t1;   // [kk] = s_kk/2 exp(-i pi kk/(2N))
   const T* t2;   // [kk] = conj(s_(M-kk)/2 exp(-i pi (M-kk)/(2N)))
@@ -190,18 +205,19 @@ __device__ __forceinline__ void ldc(const T* __restrict__ tab, int idx, T& r, T&
   }
 }
 
-// Group-level synchronisation of the LDS exchange.  A group never spans wavefronts and
-// the LDS executes one wave's accesses in issue order, so no s_barrier is needed: the
-// wavefront-scope fences only keep the COMPILER from moving LDS accesses across the point
-// where other lanes of the same wave take over the data.
+// Group-level synchronisation of the LDS exchange.  A group inside one wavefront needs no
+// s_barrier (the LDS executes one wave's accesses in issue order): wavefront-scope fences
+// keep the COMPILER from moving LDS accesses across the hand-over point.  A group spanning
+// wavefronts uses the workgroup barrier.
+template <class C>
 __device__ __forceinline__ void xsync() {
-#ifdef CHS_XSYNC_BLOCK
-  __syncthreads();
-#else
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
+  if constexpr (C::WAVE_LOCAL) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -278,117 +294,220 @@ __device__ __forceinline__ void slot_adj(T y0, T y1, T y2, T y3, const FTables<T
 // ---------------------------------------------------------------------------
 
 // ===========================================================================
-// Forward radix passes.  In: re/im[E] = pass-0 operands, index ((q*2+b)*R0 + j).
-// Out: re/im[E] = last-pass outputs Z, index ((q*2+b)*R2 + k)  (b = 0: kappa1, 1: kappa2).
+// Radix passes.  Register index conventions:
+//   pass 0 operands / results   ((q*2+b)*R0 + j)   q < NP0 mirror pairs, b: m1 | m2 = L1-1-m1
+//   pass A / pass B             (ib*R + j)          butterfly id = l + G*ib -> (kappa = id % S, m = id / S)
+//   last pass                   ((q*2+b)*RL + j)    q < NP2 mirror pairs, b: kappa1 | kappa2
+// Exchange buffers (real and imaginary parts travel one after the other through `scr`):
+//   X1[kappa][m] at kappa*P1 + m,  X2[kappa][m] at kappa*P2 + m,  XL[m][kappa] at m*PL + kappa.
 // ===========================================================================
-template <class C>
-__device__ __forceinline__ void fwd_passes(typename C::T* re, typename C::T* im, typename C::T* scr,
-                                           const FTables<typename C::T>& tb, int l) {
+
+// one middle pass of the forward transform, in registers
+template <class C, int S_IN, int L_OUT, int R, int NB>
+__device__ __forceinline__ void mid_fwd(typename C::T* re, typename C::T* im, const typename C::T* tw, int l) {
   using T = typename C::T;
-  constexpr int R0 = C::R0, R1 = C::R1, R2 = C::R2;
-  // ---- pass 0: radix R0 on every owned butterfly, then twiddle by omega_M^(m k0)
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) {
+    const int mm = (l + C::G * ib) / S_IN;
+    T* r = re + ib * R;
+    T* i = im + ib * R;
+    Dft<T, R, false>::run(r, i);
+#pragma unroll
+    for (int k = 1; k < R; ++k) {
+      T wr, wi;
+      ldc(tw, (k - 1) * L_OUT + mm, wr, wi);
+      cmul<T, false>(r[k], i[k], wr, wi);
+    }
+  }
+}
+template <class C, int S_IN, int L_OUT, int R, int NB>
+__device__ __forceinline__ void mid_inv(typename C::T* re, typename C::T* im, const typename C::T* tw, int l) {
+  using T = typename C::T;
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) {
+    const int mm = (l + C::G * ib) / S_IN;
+    T* r = re + ib * R;
+    T* i = im + ib * R;
+#pragma unroll
+    for (int k = 1; k < R; ++k) {
+      T wr, wi;
+      ldc(tw, (k - 1) * L_OUT + mm, wr, wi);
+      cmul<T, true>(r[k], i[k], wr, wi);
+    }
+    Dft<T, R, true>::run(r, i);
+  }
+}
+
+// ---- register <-> LDS movers; WR = true: registers -> LDS, false: LDS -> registers
+template <class C, bool WR>
+__device__ __forceinline__ void xfer(typename C::T& reg, typename C::T* scr, int addr) {
+  if constexpr (WR) scr[addr] = reg; else reg = scr[addr];
+}
+// pass-0 results (q,b,k) <-> X1[k][m_b]   (or XL[m_b][k] when there is no middle pass)
+template <class C, bool WR>
+__device__ __forceinline__ void mv_pass0(typename C::T* v, typename C::T* scr, int l) {
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
     const int m1 = l + C::G * q;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int m = b ? (C::L1 - 1 - m1) : m1;
-      T* r = re + (q * 2 + b) * R0;
-      T* i = im + (q * 2 + b) * R0;
-      Dft<T, R0, false>::run(r, i);
 #pragma unroll
-      for (int k = 1; k < R0; ++k) {
+      for (int k = 0; k < C::R0; ++k) {
+        if constexpr (C::RA > 1) xfer<C, WR>(v[(q * 2 + b) * C::R0 + k], scr, k * C::P1 + m);
+        else xfer<C, WR>(v[(q * 2 + b) * C::R0 + k], scr, m * C::PL + k);
+      }
+    }
+  }
+}
+// pass-A operands (ib,j) <-> X1[kappa][mm + L2*j]
+template <class C, bool WR>
+__device__ __forceinline__ void mv_a_in(typename C::T* v, typename C::T* scr, int l) {
+#pragma unroll
+  for (int ib = 0; ib < C::NBA; ++ib) {
+    const int id = l + C::G * ib;
+    const int kap = id % C::S1, mm = id / C::S1;
+#pragma unroll
+    for (int j = 0; j < C::RA; ++j) xfer<C, WR>(v[ib * C::RA + j], scr, kap * C::P1 + mm + C::L2 * j);
+  }
+}
+// pass-A results (ib,k) <-> X2[kappa + S1*k][mm]   (or XL[mm][kappa + S1*k] when pass B is absent)
+template <class C, bool WR>
+__device__ __forceinline__ void mv_a_out(typename C::T* v, typename C::T* scr, int l) {
+#pragma unroll
+  for (int ib = 0; ib < C::NBA; ++ib) {
+    const int id = l + C::G * ib;
+    const int kap = id % C::S1, mm = id / C::S1;
+#pragma unroll
+    for (int k = 0; k < C::RA; ++k) {
+      if constexpr (C::RB > 1) xfer<C, WR>(v[ib * C::RA + k], scr, (kap + C::S1 * k) * C::P2 + mm);
+      else xfer<C, WR>(v[ib * C::RA + k], scr, mm * C::PL + kap + C::S1 * k);
+    }
+  }
+}
+// pass-B operands (ib,j) <-> X2[kappa][mm + L3*j]
+template <class C, bool WR>
+__device__ __forceinline__ void mv_b_in(typename C::T* v, typename C::T* scr, int l) {
+#pragma unroll
+  for (int ib = 0; ib < C::NBB; ++ib) {
+    const int id = l + C::G * ib;
+    const int kap = id % C::S2A, mm = id / C::S2A;
+#pragma unroll
+    for (int j = 0; j < C::RB; ++j) xfer<C, WR>(v[ib * C::RB + j], scr, kap * C::P2 + mm + C::L3 * j);
+  }
+}
+// pass-B results (ib,k) <-> XL[mm][kappa + S2A*k]
+template <class C, bool WR>
+__device__ __forceinline__ void mv_b_out(typename C::T* v, typename C::T* scr, int l) {
+#pragma unroll
+  for (int ib = 0; ib < C::NBB; ++ib) {
+    const int id = l + C::G * ib;
+    const int kap = id % C::S2A, mm = id / C::S2A;
+#pragma unroll
+    for (int k = 0; k < C::RB; ++k) xfer<C, WR>(v[ib * C::RB + k], scr, mm * C::PL + kap + C::S2A * k);
+  }
+}
+// last-pass operands (q,b,j) <-> XL[j][kappa_b]
+template <class C, bool WR>
+__device__ __forceinline__ void mv_last(typename C::T* v, typename C::T* scr, int l) {
+#pragma unroll
+  for (int q = 0; q < C::NP2; ++q) {
+    int k1, k2; bool sp;
+    Own<C>::last_pair(l, q, k1, k2, sp);
+#pragma unroll
+    for (int j = 0; j < C::RL; ++j) {
+      xfer<C, WR>(v[(q * 2 + 0) * C::RL + j], scr, j * C::PL + k1);
+      xfer<C, WR>(v[(q * 2 + 1) * C::RL + j], scr, j * C::PL + k2);
+    }
+  }
+}
+
+// one exchange: WRITER moves the registers out, READER brings the new ownership in
+#define CHS_EXCHANGE(WRITER, READER)              \
+  do {                                            \
+    xsync<C>(); WRITER(re, scr, l); xsync<C>(); READER(re, scr, l); \
+    xsync<C>(); WRITER(im, scr, l); xsync<C>(); READER(im, scr, l); \
+  } while (0)
+
+// Forward: pass-0 operands in -> last-pass outputs Z out (index ((q*2+b)*RL + k)).
+template <class C>
+__device__ __forceinline__ void fwd_passes(typename C::T* re, typename C::T* im, typename C::T* scr,
+                                           const FTables<typename C::T>& tb, int l) {
+  using T = typename C::T;
+  // ---- pass 0: radix R0 on every owned butterfly, then twiddle by omega_M^(m k)
+#pragma unroll
+  for (int q = 0; q < C::NP0; ++q) {
+    const int m1 = l + C::G * q;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int m = b ? (C::L1 - 1 - m1) : m1;
+      T* r = re + (q * 2 + b) * C::R0;
+      T* i = im + (q * 2 + b) * C::R0;
+      Dft<T, C::R0, false>::run(r, i);
+#pragma unroll
+      for (int k = 1; k < C::R0; ++k) {
         T wr, wi;
         ldc(tb.tw0, (k - 1) * C::L1 + m, wr, wi);
         cmul<T, false>(r[k], i[k], wr, wi);
       }
     }
   }
-  T xr[C::E], xi[C::E];
-  if constexpr (R1 > 1) {
-    // ---- exchange A1[k0][m'] -> pass-1 operands (kappa = id % S1, m'' = id / S1)
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-      T* src = part ? im : re;
-      T* dst = part ? xi : xr;
-      xsync();
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int m1 = l + C::G * q;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int m = b ? (C::L1 - 1 - m1) : m1;
-#pragma unroll
-          for (int k = 0; k < R0; ++k) scr[k * C::P1 + m] = src[(q * 2 + b) * R0 + k];
-        }
-      }
-      xsync();
-#pragma unroll
-      for (int ib = 0; ib < C::NB1; ++ib) {
-        const int id = l + C::G * ib;
-        const int kap = id % C::S1, mm = id / C::S1;
-#pragma unroll
-        for (int j = 0; j < R1; ++j) dst[ib * R1 + j] = scr[kap * C::P1 + mm + C::L2 * j];
-      }
-    }
-    // ---- pass 1
-#pragma unroll
-    for (int ib = 0; ib < C::NB1; ++ib) {
-      const int id = l + C::G * ib;
-      const int mm = id / C::S1;
-      T* r = xr + ib * R1;
-      T* i = xi + ib * R1;
-      Dft<T, R1, false>::run(r, i);
-#pragma unroll
-      for (int k = 1; k < R1; ++k) {
-        T wr, wi;
-        ldc(tb.tw1, (k - 1) * C::L2 + mm, wr, wi);
-        cmul<T, false>(r[k], i[k], wr, wi);
-      }
-    }
-  }
-  // ---- exchange into A2[m''][kappa] -> last-pass operands
-#pragma unroll
-  for (int part = 0; part < 2; ++part) {
-    xsync();
-    if constexpr (R1 > 1) {
-      T* src = part ? xi : xr;
-#pragma unroll
-      for (int ib = 0; ib < C::NB1; ++ib) {
-        const int id = l + C::G * ib;
-        const int kap = id % C::S1, mm = id / C::S1;
-#pragma unroll
-        for (int k = 0; k < R1; ++k) scr[mm * C::P2 + kap + C::S1 * k] = src[ib * R1 + k];
-      }
+  if constexpr (C::RA > 1) {
+    CHS_EXCHANGE((mv_pass0<C, true>), (mv_a_in<C, false>));
+    mid_fwd<C, C::S1, C::L2, C::RA, C::NBA>(re, im, tb.twa, l);
+    if constexpr (C::RB > 1) {
+      CHS_EXCHANGE((mv_a_out<C, true>), (mv_b_in<C, false>));
+      mid_fwd<C, C::S2A, C::L3, C::RB, C::NBB>(re, im, tb.twb, l);
+      CHS_EXCHANGE((mv_b_out<C, true>), (mv_last<C, false>));
     } else {
-      T* src = part ? im : re;
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int m1 = l + C::G * q;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int m = b ? (C::L1 - 1 - m1) : m1;
-#pragma unroll
-          for (int k = 0; k < R0; ++k) scr[m * C::P2 + k] = src[(q * 2 + b) * R0 + k];
-        }
-      }
+      CHS_EXCHANGE((mv_a_out<C, true>), (mv_last<C, false>));
     }
-    xsync();
-    T* dst = part ? im : re;
-#pragma unroll
-    for (int q = 0; q < C::NP2; ++q) {
-      int k1, k2; bool sp;
-      Own<C>::last_pair(l, q, k1, k2, sp);
-#pragma unroll
-      for (int mm = 0; mm < R2; ++mm) {
-        dst[(q * 2 + 0) * R2 + mm] = scr[mm * C::P2 + k1];
-        dst[(q * 2 + 1) * R2 + mm] = scr[mm * C::P2 + k2];
-      }
-    }
+  } else {
+    CHS_EXCHANGE((mv_pass0<C, true>), (mv_last<C, false>));
   }
   // ---- last pass
 #pragma unroll
-  for (int q = 0; q < 2 * C::NP2; ++q) Dft<T, R2, false>::run(re + q * R2, im + q * R2);
+  for (int q = 0; q < 2 * C::NP2; ++q) Dft<T, C::RL, false>::run(re + q * C::RL, im + q * C::RL);
+}
+
+// Inverse (exact transpose): last-pass output gradients in -> pass-0 operands out.
+template <class C>
+__device__ __forceinline__ void inv_passes(typename C::T* re, typename C::T* im, typename C::T* scr,
+                                           const FTables<typename C::T>& tb, int l) {
+  using T = typename C::T;
+#pragma unroll
+  for (int q = 0; q < 2 * C::NP2; ++q) Dft<T, C::RL, true>::run(re + q * C::RL, im + q * C::RL);
+  if constexpr (C::RA > 1) {
+    if constexpr (C::RB > 1) {
+      CHS_EXCHANGE((mv_last<C, true>), (mv_b_out<C, false>));
+      mid_inv<C, C::S2A, C::L3, C::RB, C::NBB>(re, im, tb.twb, l);
+      CHS_EXCHANGE((mv_b_in<C, true>), (mv_a_out<C, false>));
+    } else {
+      CHS_EXCHANGE((mv_last<C, true>), (mv_a_out<C, false>));
+    }
+    mid_inv<C, C::S1, C::L2, C::RA, C::NBA>(re, im, tb.twa, l);
+    CHS_EXCHANGE((mv_a_in<C, true>), (mv_pass0<C, false>));
+  } else {
+    CHS_EXCHANGE((mv_last<C, true>), (mv_pass0<C, false>));
+  }
+  // ---- pass 0 transposed
+#pragma unroll
+  for (int q = 0; q < C::NP0; ++q) {
+    const int m1 = l + C::G * q;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int m = b ? (C::L1 - 1 - m1) : m1;
+      T* r = re + (q * 2 + b) * C::R0;
+      T* i = im + (q * 2 + b) * C::R0;
+#pragma unroll
+      for (int k = 1; k < C::R0; ++k) {
+        T wr, wi;
+        ldc(tb.tw0, (k - 1) * C::L1 + m, wr, wi);
+        cmul<T, true>(r[k], i[k], wr, wi);
+      }
+      Dft<T, C::R0, true>::run(r, i);
+    }
+  }
 }
 
 // ===========================================================================
@@ -460,122 +579,6 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
         f((q * R2 + R2 / 2 + k) * 4, idx, y);
         if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], tb, kk, r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
       }
-    }
-  }
-}
-
-// ===========================================================================
-// Inverse radix passes (exact transpose of fwd_passes).  In: re/im[E] = last-pass
-// output gradients, index ((q*2+b)*R2 + k).  Out: pass-0 operands ((q*2+b)*R0 + j).
-// ===========================================================================
-template <class C>
-__device__ __forceinline__ void inv_passes(typename C::T* re, typename C::T* im, typename C::T* scr,
-                                           const FTables<typename C::T>& tb, int l) {
-  using T = typename C::T;
-  constexpr int R0 = C::R0, R1 = C::R1, R2 = C::R2;
-#pragma unroll
-  for (int q = 0; q < 2 * C::NP2; ++q) Dft<T, R2, true>::run(re + q * R2, im + q * R2);
-  // ---- exchange A2[m''][kappa] back
-  T xr[C::E], xi[C::E];
-#pragma unroll
-  for (int part = 0; part < 2; ++part) {
-    const T* src = part ? im : re;
-    xsync();
-#pragma unroll
-    for (int q = 0; q < C::NP2; ++q) {
-      int k1, k2; bool sp;
-      Own<C>::last_pair(l, q, k1, k2, sp);
-#pragma unroll
-      for (int mm = 0; mm < R2; ++mm) {
-        scr[mm * C::P2 + k1] = src[(q * 2 + 0) * R2 + mm];
-        scr[mm * C::P2 + k2] = src[(q * 2 + 1) * R2 + mm];
-      }
-    }
-    xsync();
-    if constexpr (R1 > 1) {
-      T* dst = part ? xi : xr;
-#pragma unroll
-      for (int ib = 0; ib < C::NB1; ++ib) {
-        const int id = l + C::G * ib;
-        const int kap = id % C::S1, mm = id / C::S1;
-#pragma unroll
-        for (int k = 0; k < R1; ++k) dst[ib * R1 + k] = scr[mm * C::P2 + kap + C::S1 * k];
-      }
-    } else {
-      T* dst = part ? xi : xr;
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int m1 = l + C::G * q;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int m = b ? (C::L1 - 1 - m1) : m1;
-#pragma unroll
-          for (int k = 0; k < R0; ++k) dst[(q * 2 + b) * R0 + k] = scr[m * C::P2 + k];
-        }
-      }
-    }
-  }
-  if constexpr (R1 > 1) {
-    // ---- pass 1 transposed: conj twiddle, conjugate DFT
-#pragma unroll
-    for (int ib = 0; ib < C::NB1; ++ib) {
-      const int id = l + C::G * ib;
-      const int mm = id / C::S1;
-      T* r = xr + ib * R1;
-      T* i = xi + ib * R1;
-#pragma unroll
-      for (int k = 1; k < R1; ++k) {
-        T wr, wi;
-        ldc(tb.tw1, (k - 1) * C::L2 + mm, wr, wi);
-        cmul<T, true>(r[k], i[k], wr, wi);
-      }
-      Dft<T, R1, true>::run(r, i);
-    }
-    // ---- exchange A1[k0][m'] back
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-      const T* src = part ? xi : xr;
-      T* dst = part ? im : re;
-      xsync();
-#pragma unroll
-      for (int ib = 0; ib < C::NB1; ++ib) {
-        const int id = l + C::G * ib;
-        const int kap = id % C::S1, mm = id / C::S1;
-#pragma unroll
-        for (int j = 0; j < R1; ++j) scr[kap * C::P1 + mm + C::L2 * j] = src[ib * R1 + j];
-      }
-      xsync();
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int m1 = l + C::G * q;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int m = b ? (C::L1 - 1 - m1) : m1;
-#pragma unroll
-          for (int k = 0; k < R0; ++k) dst[(q * 2 + b) * R0 + k] = scr[k * C::P1 + m];
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < C::E; ++e) { re[e] = xr[e]; im[e] = xi[e]; }
-  }
-  // ---- pass 0 transposed
-#pragma unroll
-  for (int q = 0; q < C::NP0; ++q) {
-    const int m1 = l + C::G * q;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int m = b ? (C::L1 - 1 - m1) : m1;
-      T* r = re + (q * 2 + b) * R0;
-      T* i = im + (q * 2 + b) * R0;
-#pragma unroll
-      for (int k = 1; k < R0; ++k) {
-        T wr, wi;
-        ldc(tb.tw0, (k - 1) * C::L1 + m, wr, wi);
-        cmul<T, true>(r[k], i[k], wr, wi);
-      }
-      Dft<T, R0, true>::run(r, i);
     }
   }
 }
