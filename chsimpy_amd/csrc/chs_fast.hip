@@ -241,6 +241,7 @@ struct ColStage {
   static constexpr int ELEMS = LINES * LP;     // staging elements
   static constexpr int JR = C::R0 / 4;         // pass-0 half-indices j per round
   static_assert(C::R0 >= 4, "pass-0 radix must be >= 4");
+  static_assert((LINES * LINE) % (2 * C::THREADS) == 0, "the tile must split evenly over the threads");
 };
 
 template <class C>
@@ -266,24 +267,35 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   T re[C::E], im[C::E];
 
   if constexpr (MODE != MODE_INV_NATURAL) {
-    // ---- stage in: tile rows -> quads of this group's column
+    // ---- stage in: tile rows -> quads of this group's column.  The whole tile is requested
+    // first (one HBM latency for both rounds), then it passes through LDS half by half.
     const T* tile = Tin + (size_t)ct * C::N * C::C;
+    constexpr int PER = CS::LINES * CS::LINE / (2 * C::THREADS);  // 16-byte loads per thread per round
+    T stage[2][2 * PER];
+#pragma unroll
+    for (int rho = 0; rho < 2; ++rho) {
+      const T* src = tile + (size_t)rho * CS::LINES * CS::LINE;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int f = 2 * (threadIdx.x + i * C::THREADS);
+        if constexpr (sizeof(T) == 8) {
+          const double2 v = *reinterpret_cast<const double2*>(src + f);
+          stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
+        } else {
+          const float2 v = *reinterpret_cast<const float2*>(src + f);
+          stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
+        }
+      }
+    }
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
       __syncthreads();
-      const T* src = tile + (size_t)rho * CS::LINES * CS::LINE;
-      for (int f = 2 * threadIdx.x; f < CS::LINES * CS::LINE; f += 2 * C::THREADS) {
-        T a, b;
-        if constexpr (sizeof(T) == 8) {
-          const double2 v = *reinterpret_cast<const double2*>(src + f);
-          a = v.x; b = v.y;
-        } else {
-          const float2 v = *reinterpret_cast<const float2*>(src + f);
-          a = v.x; b = v.y;
-        }
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int f = 2 * (threadIdx.x + i * C::THREADS);
         const int line = f / CS::LINE, off = f % CS::LINE;
-        lds[line * CS::LP + off] = a;
-        lds[line * CS::LP + off + 1] = b;
+        lds[line * CS::LP + off] = stage[rho][2 * i];
+        lds[line * CS::LP + off + 1] = stage[rho][2 * i + 1];
       }
       __syncthreads();
 #pragma unroll
@@ -399,11 +411,12 @@ static FTables<T> get_tables(Engine* E) {
   return tb;
 }
 
-template <class C>
+template <class C, class CC = C>
 struct Launch {
   using T = typename C::T;
   static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T);
-  static constexpr size_t col_lds = (size_t)col_lds_elems<C>() * sizeof(T);
+  static constexpr size_t col_lds = (size_t)col_lds_elems<CC>() * sizeof(T);
+  static_assert(C::N == CC::N && C::C == CC::C && C::THREADS == CC::THREADS, "row/column configs must agree on the tile layout");
 
   template <class K>
   static int set_lds(K kernel, size_t bytes) {
@@ -418,10 +431,10 @@ struct Launch {
     if ((rc = set_lds(k_row_inv<C, false, false>, row_lds))) return rc;
     if ((rc = set_lds(k_row_inv<C, true, false>, row_lds))) return rc;
     if ((rc = set_lds(k_row_inv<C, true, true>, row_lds))) return rc;
-    if ((rc = set_lds(k_col<C, MODE_STEP>, col_lds))) return rc;
-    if ((rc = set_lds(k_col<C, MODE_FWD_NATIVE>, col_lds))) return rc;
-    if ((rc = set_lds(k_col<C, MODE_FWD_NATURAL>, col_lds))) return rc;
-    if ((rc = set_lds(k_col<C, MODE_INV_NATURAL>, col_lds))) return rc;
+    if ((rc = set_lds(k_col<CC, MODE_STEP>, col_lds))) return rc;
+    if ((rc = set_lds(k_col<CC, MODE_FWD_NATIVE>, col_lds))) return rc;
+    if ((rc = set_lds(k_col<CC, MODE_FWD_NATURAL>, col_lds))) return rc;
+    if ((rc = set_lds(k_col<CC, MODE_INV_NATURAL>, col_lds))) return rc;
     return CHS_OK;
   }
   static int row_fwd(Engine* E, const void* in, void* out, bool pointwise) {
@@ -455,16 +468,16 @@ struct Launch {
     const FTables<T> tb = get_tables<T>(E);
     switch (mode) {
       case MODE_STEP:
-        k_col<C, MODE_STEP><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_STEP><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       case MODE_FWD_NATIVE:
-        k_col<C, MODE_FWD_NATIVE><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_FWD_NATIVE><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       case MODE_FWD_NATURAL:
-        k_col<C, MODE_FWD_NATURAL><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_FWD_NATURAL><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       default:
-        k_col<C, MODE_INV_NATURAL><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_INV_NATURAL><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
     }
     CHS_HIP(hipGetLastError());
@@ -480,14 +493,15 @@ using F1024 = FCfg<double, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
 using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 // N = 4096: two wavefronts per transform, 16 complex values per lane, four radix passes
 using F4096 = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 4>;
+using F4096C = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 4, true>;  // k_col: wave-owned sub-transforms
 
-template <class C>
+template <class C, class CC = C>
 static void bind(FastPlan* P) {
   P->N = C::N; P->G = C::G; P->R0 = C::R0; P->RA = C::RA; P->RB = C::RB; P->RL = C::RL; P->threads = C::THREADS;
-  P->row_fwd = &Launch<C>::row_fwd;
-  P->row_inv = &Launch<C>::row_inv;
-  P->col = &Launch<C>::col;
-  P->init = &Launch<C>::init;
+  P->row_fwd = &Launch<C, CC>::row_fwd;
+  P->row_inv = &Launch<C, CC>::row_inv;
+  P->col = &Launch<C, CC>::col;
+  P->init = &Launch<C, CC>::init;
 }
 
 bool chs_fast_supported(int N, int dtype) {
@@ -562,7 +576,7 @@ int chs_fast_init(Engine* E) {
     case 512: bind<F512>(P); break;
     case 1024: bind<F1024>(P); break;
     case 2048: bind<F2048>(P); break;
-    case 4096: bind<F4096>(P); break;
+    case 4096: bind<F4096, F4096C>(P); break;
     default: delete P; chs_set_error("fast engine: unsupported N"); return CHS_EINVAL;
   }
   E->dTw = P;
