@@ -493,7 +493,6 @@ using F1024 = FCfg<double, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
 using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 // N = 4096: two wavefronts per transform, 16 complex values per lane, four radix passes
 using F4096 = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 4>;
-using F4096C = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 4, true>;  // k_col: wave-owned sub-transforms
 
 template <class C, class CC = C>
 static void bind(FastPlan* P) {
@@ -576,7 +575,7 @@ int chs_fast_init(Engine* E) {
     case 512: bind<F512>(P); break;
     case 1024: bind<F1024>(P); break;
     case 2048: bind<F2048>(P); break;
-    case 4096: bind<F4096, F4096C>(P); break;
+    case 4096: bind<F4096>(P); break;
     default: delete P; chs_set_error("fast engine: unsupported N"); return CHS_EINVAL;
   }
   E->dTw = P;

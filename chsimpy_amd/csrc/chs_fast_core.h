@@ -22,7 +22,7 @@
 // compile-time configuration
 // ---------------------------------------------------------------------------
 template <typename T_, int N_, int G_, int THREADS_, int R0_, int RA_, int RB_, int RL_, int PAD1_, int PAD2_,
-          int PADL_, int WPS_, bool REMAP_ = false>
+          int PADL_, int WPS_>
 struct FCfg {
   using T = T_;
   static constexpr int N = N_;
@@ -54,25 +54,6 @@ struct FCfg {
   static constexpr int SCRL = RL_ * PL;
   static constexpr int SCR = (SCR1 > SCR2 ? (SCR1 > SCRL ? SCR1 : SCRL) : (SCR2 > SCRL ? SCR2 : SCRL));
   static constexpr bool WAVE_LOCAL = (G_ <= 64);  // a group inside one wavefront needs no s_barrier
-  // REMAP (two-wave groups, R0 = 8): after pass 0 the transform falls apart into R0 independent
-  // sub-transforms (one per first frequency digit k0).  Passes A, B and the last pass are then
-  // owned through a VIRTUAL lane number chosen so that each wavefront holds whole sub-transforms
-  // (k0 in {0,4,1,7} | {2,6,3,5}: both sets closed under k0 -> R0-k0, which the mirror pairs of the
-  // last pass need).  Only the pass-0 <-> pass-A exchange then crosses wavefronts; the later ones
-  // need no s_barrier.  The coefficient a lane ends up with changes, so REMAP is used where no HBM
-  // address depends on it (k_col: hat_U lives in the kernel's own order).
-  static constexpr bool REMAP = REMAP_;
-  static_assert(!REMAP_ || (G_ == 128 && R0_ == 8 && RA_ > 1), "REMAP needs G = 128, R0 = 8, a middle pass");
-  static __device__ __forceinline__ int vlane(int l) {
-    if constexpr (!REMAP_) {
-      return l;
-    } else {
-      const int w = l >> 6, r = l & 3, h = (l & 63) >> 2;
-      // wave 0: {0,4,1,7}[r]   wave 1: {2,6,3,5}[r]
-      const int k0 = w ? ((r == 0) ? 2 : (r == 1) ? 6 : (r == 2) ? 3 : 5) : ((r == 0) ? 0 : (r == 1) ? 4 : (r == 2) ? 1 : 7);
-      return h * 8 + k0;
-    }
-  }
   static_assert(L3 == RL_, "radices must multiply to M");
   static_assert(RA_ > 1 || RB_ == 1, "use RA before RB");
   static_assert(NP0 >= 1 && NP2 >= 1, "E must be >= 2*R0 and >= 2*RL");
@@ -228,10 +209,9 @@ __device__ __forceinline__ void ldc(const T* __restrict__ tab, int idx, T& r, T&
 // s_barrier (the LDS executes one wave's accesses in issue order): wavefront-scope fences
 // keep the COMPILER from moving LDS accesses across the hand-over point.  A group spanning
 // wavefronts uses the workgroup barrier.
-template <class C, bool CROSS = true>
+template <class C>
 __device__ __forceinline__ void xsync() {
-  // CROSS = false: an exchange that stays inside a wavefront thanks to REMAP
-  if constexpr (C::WAVE_LOCAL || (C::REMAP && !CROSS)) {
+  if constexpr (C::WAVE_LOCAL) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -443,11 +423,10 @@ __device__ __forceinline__ void mv_last(typename C::T* v, typename C::T* scr, in
 }
 
 // one exchange: WRITER moves the registers out, READER brings the new ownership in
-// (LW / LR: the lane number the writer / reader side is owned through; CROSS: see xsync)
-#define CHS_EXCHANGE(CROSS, WRITER, LW, READER, LR)                               \
-  do {                                                                            \
-    xsync<C, CROSS>(); WRITER(re, scr, LW); xsync<C, CROSS>(); READER(re, scr, LR); \
-    xsync<C, CROSS>(); WRITER(im, scr, LW); xsync<C, CROSS>(); READER(im, scr, LR); \
+#define CHS_EXCHANGE(WRITER, READER)              \
+  do {                                            \
+    xsync<C>(); WRITER(re, scr, l); xsync<C>(); READER(re, scr, l); \
+    xsync<C>(); WRITER(im, scr, l); xsync<C>(); READER(im, scr, l); \
   } while (0)
 
 // Forward: pass-0 operands in -> last-pass outputs Z out (index ((q*2+b)*RL + k)).
@@ -473,19 +452,18 @@ __device__ __forceinline__ void fwd_passes(typename C::T* re, typename C::T* im,
       }
     }
   }
-  const int lv = C::vlane(l);  // ownership of every pass after pass 0
   if constexpr (C::RA > 1) {
-    CHS_EXCHANGE(true, (mv_pass0<C, true>), l, (mv_a_in<C, false>), lv);
-    mid_fwd<C, C::S1, C::L2, C::RA, C::NBA>(re, im, tb.twa, lv);
+    CHS_EXCHANGE((mv_pass0<C, true>), (mv_a_in<C, false>));
+    mid_fwd<C, C::S1, C::L2, C::RA, C::NBA>(re, im, tb.twa, l);
     if constexpr (C::RB > 1) {
-      CHS_EXCHANGE(false, (mv_a_out<C, true>), lv, (mv_b_in<C, false>), lv);
-      mid_fwd<C, C::S2A, C::L3, C::RB, C::NBB>(re, im, tb.twb, lv);
-      CHS_EXCHANGE(false, (mv_b_out<C, true>), lv, (mv_last<C, false>), lv);
+      CHS_EXCHANGE((mv_a_out<C, true>), (mv_b_in<C, false>));
+      mid_fwd<C, C::S2A, C::L3, C::RB, C::NBB>(re, im, tb.twb, l);
+      CHS_EXCHANGE((mv_b_out<C, true>), (mv_last<C, false>));
     } else {
-      CHS_EXCHANGE(false, (mv_a_out<C, true>), lv, (mv_last<C, false>), lv);
+      CHS_EXCHANGE((mv_a_out<C, true>), (mv_last<C, false>));
     }
   } else {
-    CHS_EXCHANGE(true, (mv_pass0<C, true>), l, (mv_last<C, false>), lv);
+    CHS_EXCHANGE((mv_pass0<C, true>), (mv_last<C, false>));
   }
   // ---- last pass
 #pragma unroll
@@ -499,19 +477,18 @@ __device__ __forceinline__ void inv_passes(typename C::T* re, typename C::T* im,
   using T = typename C::T;
 #pragma unroll
   for (int q = 0; q < 2 * C::NP2; ++q) Dft<T, C::RL, true>::run(re + q * C::RL, im + q * C::RL);
-  const int lv = C::vlane(l);
   if constexpr (C::RA > 1) {
     if constexpr (C::RB > 1) {
-      CHS_EXCHANGE(false, (mv_last<C, true>), lv, (mv_b_out<C, false>), lv);
-      mid_inv<C, C::S2A, C::L3, C::RB, C::NBB>(re, im, tb.twb, lv);
-      CHS_EXCHANGE(false, (mv_b_in<C, true>), lv, (mv_a_out<C, false>), lv);
+      CHS_EXCHANGE((mv_last<C, true>), (mv_b_out<C, false>));
+      mid_inv<C, C::S2A, C::L3, C::RB, C::NBB>(re, im, tb.twb, l);
+      CHS_EXCHANGE((mv_b_in<C, true>), (mv_a_out<C, false>));
     } else {
-      CHS_EXCHANGE(false, (mv_last<C, true>), lv, (mv_a_out<C, false>), lv);
+      CHS_EXCHANGE((mv_last<C, true>), (mv_a_out<C, false>));
     }
-    mid_inv<C, C::S1, C::L2, C::RA, C::NBA>(re, im, tb.twa, lv);
-    CHS_EXCHANGE(true, (mv_a_in<C, true>), lv, (mv_pass0<C, false>), l);
+    mid_inv<C, C::S1, C::L2, C::RA, C::NBA>(re, im, tb.twa, l);
+    CHS_EXCHANGE((mv_a_in<C, true>), (mv_pass0<C, false>));
   } else {
-    CHS_EXCHANGE(true, (mv_last<C, true>), lv, (mv_pass0<C, false>), l);
+    CHS_EXCHANGE((mv_last<C, true>), (mv_pass0<C, false>));
   }
   // ---- pass 0 transposed
 #pragma unroll
@@ -547,7 +524,6 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
                                           int l, F&& f) {
   using T = typename C::T;
   constexpr int R2 = C::R2, N = C::N, M = C::M;
-  l = C::vlane(l);
 #pragma unroll
   for (int q = 0; q < C::NP2; ++q) {
     int k1, k2; bool sp;
