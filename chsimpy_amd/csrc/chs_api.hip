@@ -256,13 +256,12 @@ static int enter(Engine* E) {
 }
 
 // one iteration of solver.py:165-249
-static int one_step(Engine* E, bool last) {
+static int one_step(Engine* E, bool first, bool last) {
   int rc;
   const bool jitter = E->dNoise && E->jitter > 0.0 && E->jitter < 0.1;
   if (E->engine == CHS_ENGINE_FAST && !jitter) {
-    // fused pipeline: k_pre, k_col, k_row_inv(+record partials, + next step's row pass), k_fin
-    if ((rc = chs_fast_step(E, !last))) return rc;
-    return chs_launch_fin(E, 0, 1);
+    // fused pipeline: k_col, k_row_inv (+ record partials + next step's row pass), k_step_tail
+    return chs_fast_step(E, first, last);
   }
   if (E->engine == CHS_ENGINE_DIRECT) {
     if ((rc = chs_launch_mu(E))) return rc;        // 166-175
@@ -318,7 +317,7 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
     if ((rc = chs_fast_prologue(E))) { E->timer.on = false; return rc; }
   }
   for (int64_t s = 0; s < nsteps; ++s) {
-    if ((rc = one_step(E, s == nsteps - 1))) { E->timer.on = false; return rc; }
+    if ((rc = one_step(E, s == 0, s == nsteps - 1))) { E->timer.on = false; return rc; }
     if (profile && (s % 32) == 31) timer_harvest(E);
   }
   if (profile) { timer_harvest(E); E->timer.on = false; }
@@ -369,7 +368,7 @@ extern "C" const char* chs_kernel_name(chs_handle h, int slot) {
   static const char* direct[CHS_NKERNELS] = {"k_mu", "k_pre", "k_gemm x2 (dctn)", "k_spectral", "k_gemm x2 (idctn)",
                                              "k_diag", "k_fin", "misc"};
   static const char* fast[CHS_NKERNELS] = {"k_row_fwd (prologue)", "k_pre", nullptr, "k_col", "k_row_inv (fused)",
-                                           "k_diag", "k_fin", "misc"};
+                                           "k_diag", "k_step_tail", "misc"};
   return E->engine == CHS_ENGINE_DIRECT ? direct[slot] : fast[slot];
 }
 

@@ -199,7 +199,8 @@ enum {
 
 // ---- pointwise / reduction launchers (chs_pointwise.hip) -------------------
 int chs_launch_mu(Engine* E);                 // dU -> dMU, partials
-int chs_launch_mu_colsums(Engine* E);         // dU -> per-band column sums of the adaptive-step integrand only
+int chs_launch_mu_colsums(Engine* E, int cs_offset);  // dU -> column-sum minimum of the adaptive-step integrand only
+int chs_launch_step_tail(Engine* E, int do_pre);  // fused pipeline: record of step s + time-step control of step s+1
 int chs_launch_pre(Engine* E);                // partials -> state (L2, delt, time)
 int chs_launch_spectral(Engine* E, const void* hmu);  // dHat <- (dHat + Seig*hmu)/CHeig (natural order)
 int chs_launch_sum(Engine* E, int ignore_halt);  // meanU <- mean(dU)
@@ -221,5 +222,5 @@ void chs_fast_free(Engine* E);
 int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse);  // natural in/out (tests)
 int chs_fast_enter(Engine* E);   // hat_U <- dctn(U) in engine-native order (solver.py:159)
 int chs_fast_prologue(Engine* E);          // T1 <- row DCT of EnergieEut(U) for the first step of a call
-int chs_fast_step(Engine* E, bool fuse_next); // k_pre, k_col, fused row kernel (+ diagnostics partials)
+int chs_fast_step(Engine* E, bool first, bool last); // [k_pre,] k_col, fused row kernel, k_step_tail
 int chs_fast_step_unfused(Engine* E);      // jitter path: every kernel separate, U complete in HBM

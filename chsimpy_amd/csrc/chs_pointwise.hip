@@ -12,6 +12,8 @@
 #include "chs_math.h"
 
 #define PW_THREADS 256
+#define DISPATCH_T(E, expr_d, expr_f) \
+  do { if ((E)->dtype == CHS_F64) { expr_d; } else { expr_f; } } while (0)
 #define PW_BAND 8  // rows per block in the banded sweeps
 
 // ---------------------------------------------------------------------------
@@ -22,13 +24,15 @@
 template <typename T>
 __global__ __launch_bounds__(PW_THREADS) void k_mu(const T* __restrict__ U, T* __restrict__ MU, DevConsts dc,
                                                    const DevState* __restrict__ st, double* __restrict__ partMu,
-                                                   double* __restrict__ partCol, int only_col) {
+                                                   double* __restrict__ partCol, int only_col, int cs_offset) {
   __shared__ double scratch[32];
   if (st->halt) return;
   const int N = dc.N;
   const int r0 = blockIdx.x * PW_BAND;
   const int r1 = min(r0 + PW_BAND, N);
-  const bool want_col = (dc.adaptive_time && st->computed_steps > 500 && (st->computed_steps % 2) == 0);
+  // cs_offset = 1: launched before the record of the running step has advanced computed_steps
+  const long long cs = st->computed_steps + cs_offset;
+  const bool want_col = (dc.adaptive_time && cs > 500 && (cs % 2) == 0);
   if (only_col && !want_col) return;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
   double s2 = 0.0;
@@ -54,10 +58,11 @@ __global__ __launch_bounds__(PW_THREADS) void k_mu(const T* __restrict__ U, T* _
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(PW_THREADS) void k_colmin(const double* __restrict__ partCol, int nBands, int N,
                                                        const DevState* __restrict__ st, int adaptive,
-                                                       double* __restrict__ partColMin) {
+                                                       double* __restrict__ partColMin, int cs_offset) {
   __shared__ double scratch[32];
   if (st->halt) return;
-  if (!(adaptive && st->computed_steps > 500 && (st->computed_steps % 2) == 0)) return;
+  const long long cs = st->computed_steps + cs_offset;
+  if (!(adaptive && cs > 500 && (cs % 2) == 0)) return;
   const int c = blockIdx.x * PW_THREADS + threadIdx.x;
   double s = 1.0e300;
   if (c < N) {
@@ -72,6 +77,33 @@ __global__ __launch_bounds__(PW_THREADS) void k_colmin(const double* __restrict_
 // k_pre (one block): L2 of the running step, adaptive time step, time
 // bookkeeping and the time-limit stop.
 // ---------------------------------------------------------------------------
+// thread-0 part of k_pre: solver.py:184-199,225 and utils.py:41-42
+__device__ __forceinline__ void pre_update(const DevConsts& dc, DevState* st, double musq, bool adapt, double delt_dyn) {
+#pragma clang fp contract(off)
+  const double N2 = (double)dc.N * (double)dc.N;
+  st->L2_cur = sqrt(musq) / N2;  // solver.py:225
+  double delt = st->delt;
+  if (adapt) {  // solver.py:184-188
+    const double delt_new = fmax(dc.delt0, delt_dyn);
+    if (delt_new / delt > 1.15)
+      delt = 0.75 * delt + 0.25 * delt_new;
+    else
+      delt = delt_new;
+    st->delt = delt;
+  }
+  const double lam1 = delt / dc.delx2;  // utils.py:41-42
+  st->lam1 = lam1;
+  st->lam2 = dc.kappa_tilde * lam1 / dc.delx2;
+  const double tds = st->time_delta_sum + delt;  // solver.py:195-199
+  st->time_delta_sum = tds;
+  const double tp = tds / dc.M_tilde;
+  st->time_passed = tp;
+  if (dc.time_limit_s > 0.0 && tp > dc.time_limit_s) {
+    st->stop_reason = CHS_STOP_TIME_LIMIT;
+    st->halt = 1;
+  }
+}
+
 __global__ __launch_bounds__(PW_THREADS) void k_pre(DevConsts dc, DevState* __restrict__ st,
                                                     const double* __restrict__ partMu, int nPartMu,
                                                     const double* __restrict__ partColMin, int nColMin) {
@@ -86,33 +118,7 @@ __global__ __launch_bounds__(PW_THREADS) void k_pre(DevConsts dc, DevState* __re
     for (int i = threadIdx.x; i < nColMin; i += PW_THREADS) m = fmin(m, partColMin[i]);
   }
   const double delt_dyn = block_min(m, scratch);
-  if (threadIdx.x == 0) {
-#pragma clang fp contract(off)
-    const double N2 = (double)dc.N * (double)dc.N;
-    st->L2_cur = sqrt(musq) / N2;  // solver.py:225
-    double delt = st->delt;
-    if (adapt) {  // solver.py:184-188
-      const double delt_new = fmax(dc.delt0, delt_dyn);
-      if (delt_new / delt > 1.15)
-        delt = 0.75 * delt + 0.25 * delt_new;
-      else
-        delt = delt_new;
-      st->delt = delt;
-    }
-    // utils.py:41-42
-    const double lam1 = delt / dc.delx2;
-    st->lam1 = lam1;
-    st->lam2 = dc.kappa_tilde * lam1 / dc.delx2;
-    // solver.py:195-199
-    const double tds = st->time_delta_sum + delt;
-    st->time_delta_sum = tds;
-    const double tp = tds / dc.M_tilde;
-    st->time_passed = tp;
-    if (dc.time_limit_s > 0.0 && tp > dc.time_limit_s) {
-      st->stop_reason = CHS_STOP_TIME_LIMIT;
-      st->halt = 1;
-    }
-  }
+  if (threadIdx.x == 0) pre_update(dc, st, musq, adapt, delt_dyn);
 }
 
 // ---------------------------------------------------------------------------
@@ -211,6 +217,38 @@ __global__ __launch_bounds__(PW_THREADS) void k_diag(const T* __restrict__ U, De
   }
 }
 
+// thread-0 part of the per-step record: solver.py:230-249 ; timedata.py:8-10,51-63
+__device__ __forceinline__ void fin_update(const DevConsts& dc, DevState* st, double E, double E2, double PS,
+                                           double SA, double Ra, double* __restrict__ rows, long long rowsCap) {
+  const long long k = st->rows_written;
+  if (k < rowsCap) {
+    double* row = rows + k * 9;
+    row[0] = (double)st->computed_steps; row[1] = E; row[2] = E2; row[3] = SA;
+    row[4] = st->time_passed; row[5] = Ra; row[6] = st->L2_cur; row[7] = PS; row[8] = st->delt;
+  }
+  st->rows_written = k + 1;
+  const double L2v = st->L2_cur, tp = st->time_passed;
+  if (E != E || E2 != E2 || Ra != Ra || PS != PS || L2v != L2v || tp != tp || SA != SA) {
+    st->nan_flag = 1;  // timedata.py:10 fires before computed_steps += 1
+    st->halt = 1;
+  } else {
+    const long long cs = st->computed_steps + 1;  // solver.py:240
+    st->computed_steps = cs;
+    // solver.py:242-249 ; timedata.py:63
+    if (!st->skip_check && st->E2_prev > E2 && E2 > st->E2_0) {
+      st->tau0 = (double)cs;
+      st->t0 = st->time_passed;
+      if (!dc.full_sim) {
+        st->stop_reason = CHS_STOP_ENERGY;
+        st->halt = 1;
+      } else {
+        st->skip_check = 1;
+      }
+    }
+    st->E2_prev = E2;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // k_fin (one block): reduce the sweep partials, Ra of row int(N/2)+1, write the
 // timedata row, advance the counters and apply the energy stop rule.
@@ -285,36 +323,105 @@ __global__ __launch_bounds__(PW_THREADS) void k_fin(const T* __restrict__ U, Dev
       st->nan_flag = (E != E || E2 != E2 || Ra != Ra || PS != PS) ? 1 : 0;
       st->rows_written = 0;
     } else {
-      const long long k = st->rows_written;
-      const double SA = sS / N2;
-      if (k < rowsCap) {
-        double* row = rows + k * 9;
-        row[0] = (double)st->computed_steps; row[1] = E; row[2] = E2; row[3] = SA;
-        row[4] = st->time_passed; row[5] = Ra; row[6] = st->L2_cur; row[7] = PS; row[8] = st->delt;
-      }
-      st->rows_written = k + 1;
-      const double L2v = st->L2_cur, tp = st->time_passed;
-      if (E != E || E2 != E2 || Ra != Ra || PS != PS || L2v != L2v || tp != tp || SA != SA) {
-        st->nan_flag = 1;  // timedata.py:10 fires before computed_steps += 1
-        st->halt = 1;
-      } else {
-        const long long cs = st->computed_steps + 1;  // solver.py:240
-        st->computed_steps = cs;
-        // solver.py:242-249 ; timedata.py:63
-        if (!st->skip_check && st->E2_prev > E2 && E2 > st->E2_0) {
-          st->tau0 = (double)cs;
-          st->t0 = st->time_passed;
-          if (!dc.full_sim) {
-            st->stop_reason = CHS_STOP_ENERGY;
-            st->halt = 1;
-          } else {
-            st->skip_check = 1;
-          }
-        }
-        st->E2_prev = E2;
-      }
+      fin_update(dc, st, E, E2, PS, sS / N2, Ra, rows, rowsCap);
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// k_step_tail (fast engine, fused pipeline; one block of 1024 threads): the record of step s
+// (k_fin) and, with do_pre, the time-step control of step s+1 (k_pre) in one launch.  Every
+// input is requested up front, so the block pays one memory latency instead of a dozen.
+//   partDiag[nRow][4] = {sE, column-edge terms, sPS, cSA} from k_row_inv
+//   partE2[nE2]       = spectral gradient sums from k_col
+//   partMu[nMu]       = sum(mu^2) of the NEXT step's EnergieEut from k_row_inv (fused)
+// ---------------------------------------------------------------------------
+#define TAIL_THREADS 1024
+template <typename T>
+__global__ __launch_bounds__(TAIL_THREADS) void k_step_tail(const T* __restrict__ U, DevConsts dc,
+                                                            DevState* __restrict__ st,
+                                                            const double* __restrict__ partDiag, int nRow,
+                                                            const double* __restrict__ partE2, int nE2,
+                                                            const double* __restrict__ partMu, int nMu,
+                                                            const double* __restrict__ partColMin, int nColMin,
+                                                            double* __restrict__ rows, long long rowsCap, int do_pre) {
+  constexpr int NW = TAIL_THREADS / 64, NV = 8;
+  __shared__ double red[NW * (NV + 1)];
+  __shared__ double tot[NV + 1];
+  if (st->halt) return;
+  const int N = dc.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long cs_next = st->computed_steps + 1;
+  const bool adapt = do_pre && dc.adaptive_time && cs_next > 500 && (cs_next % 2) == 0;
+  double v[NV] = {0, 0, 0, 0, 0, 0, 0, 0};  // sE, sEdge, sPS, cSA, spectral, musq, row edges, row sum
+  double mn = 1.0e300;
+  for (int i = tid; i < nRow; i += TAIL_THREADS) {
+    v[0] += partDiag[(size_t)i * 4 + 0];
+    v[1] += partDiag[(size_t)i * 4 + 1];
+    v[2] += partDiag[(size_t)i * 4 + 2];
+    v[3] += partDiag[(size_t)i * 4 + 3];
+  }
+  for (int i = tid; i < nE2; i += TAIL_THREADS) v[4] += partE2[i];
+  if (do_pre)
+    for (int i = tid; i < nMu; i += TAIL_THREADS) v[5] += partMu[i];
+  if (adapt)
+    for (int i = tid; i < nColMin; i += TAIL_THREADS) mn = fmin(mn, partColMin[i]);
+  const int rr = N / 2 + 1;  // solver.py:226-227
+  for (int c = tid; c < N; c += TAIL_THREADS) {
+    const double d0 = (double)U[(size_t)N + c] - (double)U[c];
+    const double d1 = (double)U[(size_t)(N - 1) * N + c] - (double)U[(size_t)(N - 2) * N + c];
+    v[6] += d0 * d0 + d1 * d1;
+    if (rr < N) v[7] += (double)U[(size_t)rr * N + c];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  mn = wave_min(mn);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * (NV + 1) + i] = v[i];
+    red[wave * (NV + 1) + NV] = mn;
+  }
+  __syncthreads();
+  if (tid <= NV) {
+    double t = red[tid];
+    for (int w = 1; w < NW; ++w) t = (tid < NV) ? t + red[w * (NV + 1) + tid] : fmin(t, red[w * (NV + 1) + tid]);
+    tot[tid] = t;
+  }
+  __syncthreads();
+  const double rmean = tot[7] / (double)N;
+  double s = 0.0;
+  if (rr < N)
+    for (int c = tid; c < N; c += TAIL_THREADS) s += fabs((double)U[(size_t)rr * N + c] - rmean);
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+#pragma clang fp contract(off)
+    double ra = 0.0;
+    for (int w = 0; w < NW; ++w) ra += red[w];
+    const double Ra = ra / (double)N;
+    const double N2 = (double)N * (double)N;
+    const double L2sq = dc.L * dc.L;
+    // np.gradient's sum of squares from the spectrum + the one-sided edge rows/columns (see k_fin)
+    const double sG = (4.0 * tot[4] + 3.0 * (tot[1] + tot[6])) / (4.0 * dc.delx * dc.delx);
+    const double E2 = 0.5 * dc.Amr * dc.kappa_tilde * L2sq * (sG / N2);
+    const double E = dc.Amr * L2sq * (tot[0] / N2) + E2;
+    fin_update(dc, st, E, E2, tot[2] / N2, tot[3] / N2, Ra, rows, rowsCap);
+    if (do_pre && !st->halt) pre_update(dc, st, tot[5], adapt, tot[NV]);
+  }
+}
+
+int chs_launch_step_tail(Engine* E, int do_pre) {
+  chs_slot_begin(E, SLOT_FIN);
+  DISPATCH_T(E,
+    (k_step_tail<double><<<1, TAIL_THREADS, 0, E->stream>>>((const double*)E->dU, E->dc, E->dState, E->dPartDiag,
+        E->nRowBlocks, E->dPartE2, E->nPartE2, E->dPartMu, E->nPartMu, E->dPartColMin, E->nColMinBlocks, E->dRows,
+        E->rowsCap, do_pre)),
+    (k_step_tail<float><<<1, TAIL_THREADS, 0, E->stream>>>((const float*)E->dU, E->dc, E->dState, E->dPartDiag,
+        E->nRowBlocks, E->dPartE2, E->nPartE2, E->dPartMu, E->nPartMu, E->dPartColMin, E->nColMinBlocks, E->dRows,
+        E->rowsCap, do_pre)));
+  chs_slot_end(E, SLOT_FIN);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -352,28 +459,28 @@ void chs_pointwise_free(Engine* E) {
   hipFree(E->dPartColMin); hipFree(E->dPartCol);
 }
 
-#define DISPATCH_T(E, expr_d, expr_f) \
-  do { if ((E)->dtype == CHS_F64) { expr_d; } else { expr_f; } } while (0)
 
 int chs_launch_mu(Engine* E) {
   chs_slot_begin(E, SLOT_MU);
   DISPATCH_T(E,
     (k_mu<double><<<E->nBands, PW_THREADS, 0, E->stream>>>((const double*)E->dU, (double*)E->dMU, E->dc, E->dState,
-                                                            E->dPartMu, E->dPartCol, 0)),
+                                                            E->dPartMu, E->dPartCol, 0, 0)),
     (k_mu<float><<<E->nBands, PW_THREADS, 0, E->stream>>>((const float*)E->dU, (float*)E->dMU, E->dc, E->dState,
-                                                           E->dPartMu, E->dPartCol, 0)));
+                                                           E->dPartMu, E->dPartCol, 0, 0)));
   chs_slot_end(E, SLOT_MU);
   CHS_HIP(hipGetLastError());
   return CHS_OK;
 }
 
-int chs_launch_mu_colsums(Engine* E) {
+int chs_launch_mu_colsums(Engine* E, int cs_offset) {
   chs_slot_begin(E, SLOT_MISC);
   DISPATCH_T(E,
     (k_mu<double><<<E->nBands, PW_THREADS, 0, E->stream>>>((const double*)E->dU, (double*)E->dMU, E->dc, E->dState,
-                                                            E->dPartMuAux, E->dPartCol, 1)),
+                                                            E->dPartMuAux, E->dPartCol, 1, cs_offset)),
     (k_mu<float><<<E->nBands, PW_THREADS, 0, E->stream>>>((const float*)E->dU, (float*)E->dMU, E->dc, E->dState,
-                                                           E->dPartMuAux, E->dPartCol, 1)));
+                                                           E->dPartMuAux, E->dPartCol, 1, cs_offset)));
+  k_colmin<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dPartCol, E->nBands, E->N, E->dState,
+                                                            E->dc.adaptive_time, E->dPartColMin, cs_offset);
   chs_slot_end(E, SLOT_MISC);
   CHS_HIP(hipGetLastError());
   return CHS_OK;
@@ -381,9 +488,9 @@ int chs_launch_mu_colsums(Engine* E) {
 
 int chs_launch_pre(Engine* E) {
   chs_slot_begin(E, SLOT_PRE);
-  if (E->dc.adaptive_time)
+  if (E->dc.adaptive_time && E->engine == CHS_ENGINE_DIRECT)
     k_colmin<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dPartCol, E->nBands, E->N, E->dState,
-                                                              E->dc.adaptive_time, E->dPartColMin);
+                                                              E->dc.adaptive_time, E->dPartColMin, 0);
   k_pre<<<1, PW_THREADS, 0, E->stream>>>(E->dc, E->dState, E->dPartMu, E->nPartMu, E->dPartColMin,
                                          E->nColMinBlocks);
   chs_slot_end(E, SLOT_PRE);
