@@ -158,6 +158,7 @@ struct Engine {
   double* dPartSum = nullptr;  // per-block sum(U)
   double* dPartE2 = nullptr;   // per-column-tile spectral gradient sums (fast engine)
   double* dSinSq = nullptr;    // sin^2(pi k/N), k = 0..N-1 (fast engine)
+  double* dPartRa = nullptr;   // Ra of the step, written by the row kernel (fast engine)
   int nPartE2 = 0;
   int nRowBlocks = 0;          // workgroups of the fast row kernels (diag partials)
   int nBands = 0;              // row bands used by the pointwise kernels

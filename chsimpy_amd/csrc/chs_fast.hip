@@ -132,7 +132,8 @@ template <class C, bool DIAG, bool FUSE>
 __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
                                                     typename C::T* __restrict__ T1, FTables<typename C::T> tb,
                                                     DevConsts dc, const DevState* __restrict__ st,
-                                                    double* __restrict__ partDiag, double* __restrict__ partMu) {
+                                                    double* __restrict__ partDiag, double* __restrict__ partMu,
+                                                    double* __restrict__ partRa) {
   using T = typename C::T;
   __shared__ double red[64];
   if (st->halt) return;
@@ -175,6 +176,51 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   }
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (DIAG) {
+    // Row-edge terms of np.gradient (rows 0/1 and N-2/N-1) and Ra of row int(N/2)+1
+    // (solver.py:226-227): only the two or three workgroups that own those rows take this
+    // block-uniform branch; the neighbour row is read back from HBM behind the barrier.
+    constexpr int RR = C::N / 2 + 1;
+    const bool first_blk = (blockIdx.x == 0), last_blk = (blockIdx.x == gridDim.x - 1);
+    const bool ra_blk = (blockIdx.x == RR / C::C);
+    if (first_blk || last_blk || ra_blk) {
+      __syncthreads();  // this workgroup's rows are in memory and visible to its other waves
+      const bool e0 = first_blk && sub == 0, e1 = last_blk && sub == C::C - 1;
+      if (e0 || e1) {
+        const T* other = e0 ? (U + (size_t)C::N) : (U + (size_t)(C::N - 2) * C::N);
+#pragma unroll
+        for (int q = 0; q < C::NP0; ++q) {
+          const int m1 = ls + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+          for (int j = 0; j < C::R0 / 2; ++j) {
+            T q1[4], q2[4], o1[4], o2[4];
+            unpack_quads<C>(re, im, q, j, q1, q2);
+            load4<T>(other + 4 * (size_t)(m1 + C::L1 * j), o1);
+            load4<T>(other + 4 * (size_t)(m2 + C::L1 * j), o2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const double d1 = (double)o1[e] - (double)q1[e], d2 = (double)o2[e] - (double)q2[e];
+              sEdge += d1 * d1 + d2 * d2;
+            }
+          }
+        }
+      }
+      // Ra: mean absolute deviation of one row from its own mean (two passes over registers)
+      const bool mine = ra_blk && sub == RR % C::C;
+      double rs = 0.0;
+      if (mine) {
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) rs += (double)re[e] + (double)im[e];
+      }
+      const double rmean = block_sum(rs, red) / (double)C::N;
+      double ad = 0.0;
+      if (mine) {
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) ad += fabs((double)re[e] - rmean) + fabs((double)im[e] - rmean);
+      }
+      const double ra = block_sum(ad, red) / (double)C::N;
+      if (ra_blk && threadIdx.x == 0) partRa[0] = ra;
+      __syncthreads();
+    }
     const T RT = (T)dc.RT, BRT = (T)dc.BRT, B = (T)dc.B, A0 = (T)dc.A0, A1 = (T)dc.A1;
     const double mean = st->meanU, thr = dc.threshold;
     double sE = 0.0, sPS = 0.0, cSA = 0.0, s2 = 0.0;
@@ -453,13 +499,13 @@ struct Launch {
     const FTables<T> tb = get_tables<T>(E);
     if (mode == ROW_INV_PLAIN)
       k_row_inv<C, false, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                    E->dPartDiag, E->dPartMu);
+                                                                    E->dPartDiag, E->dPartMu, E->dPartRa);
     else if (mode == ROW_INV_DIAG)
       k_row_inv<C, true, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                   E->dPartDiag, E->dPartMu);
+                                                                   E->dPartDiag, E->dPartMu, E->dPartRa);
     else
       k_row_inv<C, true, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                  E->dPartDiag, E->dPartMu);
+                                                                  E->dPartDiag, E->dPartMu, E->dPartRa);
     CHS_HIP(hipGetLastError());
     return CHS_OK;
   }
@@ -596,6 +642,7 @@ int chs_fast_init(Engine* E) {
   E->nPartMu = E->nRowBlocks;
   E->nPartE2 = E->nRowBlocks;
   CHS_HIP(hipMalloc(&E->dPartE2, sizeof(double) * (size_t)E->nPartE2));
+  CHS_HIP(hipMalloc(&E->dPartRa, sizeof(double) * 8));
   return CHS_OK;
 }
 
@@ -605,6 +652,8 @@ void chs_fast_free(Engine* E) {
   if (P->tables) hipFree(P->tables);
   if (E->dSinSq) hipFree(E->dSinSq);
   if (E->dPartE2) hipFree(E->dPartE2);
+  if (E->dPartRa) hipFree(E->dPartRa);
+  E->dPartRa = nullptr;
   E->dSinSq = nullptr; E->dPartE2 = nullptr;
   delete P;
   E->dTw = nullptr;

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(PW_THREADS) void k_fin(const T* __restrict__ U, Dev
 // k_step_tail (fast engine, fused pipeline; one block of 1024 threads): the record of step s
 // (k_fin) and, with do_pre, the time-step control of step s+1 (k_pre) in one launch.  Every
 // input is requested up front, so the block pays one memory latency instead of a dozen.
-//   partDiag[nRow][4] = {sE, column-edge terms, sPS, cSA} from k_row_inv
+//   partDiag[nRow][4] = {sE, edge-row/column terms, sPS, cSA} and partRa from k_row_inv
 //   partE2[nE2]       = spectral gradient sums from k_col
 //   partMu[nMu]       = sum(mu^2) of the NEXT step's EnergieEut from k_row_inv (fused)
 // ---------------------------------------------------------------------------
@@ -344,6 +344,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_step_tail(const T* __restrict_
                                                             const double* __restrict__ partE2, int nE2,
                                                             const double* __restrict__ partMu, int nMu,
                                                             const double* __restrict__ partColMin, int nColMin,
+                                                            const double* __restrict__ partRa,
                                                             double* __restrict__ rows, long long rowsCap, int do_pre) {
   constexpr int NW = TAIL_THREADS / 64, NV = 8;
   __shared__ double red[NW * (NV + 1)];
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_step_tail(const T* __restrict_
   const int N = dc.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long cs_next = st->computed_steps + 1;
   const bool adapt = do_pre && dc.adaptive_time && cs_next > 500 && (cs_next % 2) == 0;
-  double v[NV] = {0, 0, 0, 0, 0, 0, 0, 0};  // sE, sEdge, sPS, cSA, spectral, musq, row edges, row sum
+  double v[NV] = {0, 0, 0, 0, 0, 0, 0, 0};  // sE, sEdge, sPS, cSA, spectral, musq, -, -
   double mn = 1.0e300;
   for (int i = tid; i < nRow; i += TAIL_THREADS) {
     v[0] += partDiag[(size_t)i * 4 + 0];
@@ -365,13 +366,6 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_step_tail(const T* __restrict_
     for (int i = tid; i < nMu; i += TAIL_THREADS) v[5] += partMu[i];
   if (adapt)
     for (int i = tid; i < nColMin; i += TAIL_THREADS) mn = fmin(mn, partColMin[i]);
-  const int rr = N / 2 + 1;  // solver.py:226-227
-  for (int c = tid; c < N; c += TAIL_THREADS) {
-    const double d0 = (double)U[(size_t)N + c] - (double)U[c];
-    const double d1 = (double)U[(size_t)(N - 1) * N + c] - (double)U[(size_t)(N - 2) * N + c];
-    v[6] += d0 * d0 + d1 * d1;
-    if (rr < N) v[7] += (double)U[(size_t)rr * N + c];
-  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
   mn = wave_min(mn);
@@ -387,26 +381,21 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_step_tail(const T* __restrict_
     tot[tid] = t;
   }
   __syncthreads();
-  const double rmean = tot[7] / (double)N;
-  double s = 0.0;
-  if (rr < N)
-    for (int c = tid; c < N; c += TAIL_THREADS) s += fabs((double)U[(size_t)rr * N + c] - rmean);
-  s = wave_sum(s);
-  if (lane == 0) red[wave] = s;
-  __syncthreads();
   if (tid == 0) {
 #pragma clang fp contract(off)
-    double ra = 0.0;
-    for (int w = 0; w < NW; ++w) ra += red[w];
-    const double Ra = ra / (double)N;
+    const double Ra = partRa[0];
     const double N2 = (double)N * (double)N;
     const double L2sq = dc.L * dc.L;
     // np.gradient's sum of squares from the spectrum + the one-sided edge rows/columns (see k_fin)
-    const double sG = (4.0 * tot[4] + 3.0 * (tot[1] + tot[6])) / (4.0 * dc.delx * dc.delx);
+    const double sG = (4.0 * tot[4] + 3.0 * tot[1]) / (4.0 * dc.delx * dc.delx);
     const double E2 = 0.5 * dc.Amr * dc.kappa_tilde * L2sq * (sG / N2);
     const double E = dc.Amr * L2sq * (tot[0] / N2) + E2;
-    fin_update(dc, st, E, E2, tot[2] / N2, tot[3] / N2, Ra, rows, rowsCap);
-    if (do_pre && !st->halt) pre_update(dc, st, tot[5], adapt, tot[NV]);
+    // work on a register copy of the state: one wide load and one wide store instead of a
+    // chain of dependent global round trips
+    DevState loc = *st;
+    fin_update(dc, &loc, E, E2, tot[2] / N2, tot[3] / N2, Ra, rows, rowsCap);
+    if (do_pre && !loc.halt) pre_update(dc, &loc, tot[5], adapt, tot[NV]);
+    *st = loc;
   }
 }
 
@@ -414,11 +403,11 @@ int chs_launch_step_tail(Engine* E, int do_pre) {
   chs_slot_begin(E, SLOT_FIN);
   DISPATCH_T(E,
     (k_step_tail<double><<<1, TAIL_THREADS, 0, E->stream>>>((const double*)E->dU, E->dc, E->dState, E->dPartDiag,
-        E->nRowBlocks, E->dPartE2, E->nPartE2, E->dPartMu, E->nPartMu, E->dPartColMin, E->nColMinBlocks, E->dRows,
-        E->rowsCap, do_pre)),
+        E->nRowBlocks, E->dPartE2, E->nPartE2, E->dPartMu, E->nPartMu, E->dPartColMin, E->nColMinBlocks, E->dPartRa,
+        E->dRows, E->rowsCap, do_pre)),
     (k_step_tail<float><<<1, TAIL_THREADS, 0, E->stream>>>((const float*)E->dU, E->dc, E->dState, E->dPartDiag,
-        E->nRowBlocks, E->dPartE2, E->nPartE2, E->dPartMu, E->nPartMu, E->dPartColMin, E->nColMinBlocks, E->dRows,
-        E->rowsCap, do_pre)));
+        E->nRowBlocks, E->dPartE2, E->nPartE2, E->dPartMu, E->nPartMu, E->dPartColMin, E->nColMinBlocks, E->dPartRa,
+        E->dRows, E->rowsCap, do_pre)));
   chs_slot_end(E, SLOT_FIN);
   CHS_HIP(hipGetLastError());
   return CHS_OK;
