@@ -311,7 +311,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   const int kc = ct * C::C + sub;  // this group's column
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
-
   if constexpr (MODE != MODE_INV_NATURAL) {
     // ---- stage in: tile rows -> quads of this group's column.  The whole tile is requested
     // first (one HBM latency for both rounds), then it passes through LDS half by half.
@@ -370,6 +369,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   const double lc = lam[kc];
   const double sqc = (MODE == MODE_STEP) ? sinsq[kc] : 0.0;
   double e2 = 0.0;
+  T h00 = T(0);
   constexpr bool FWD = (MODE != MODE_INV_NATURAL);
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL);
   recombine<C, FWD, ADJ>(re, im, tb, l, [&](int pbase, const int idx[4], T y[4]) {
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         hcol[hp] = h;
         y[t] = h;
         e2 += (double)h * (double)h * (sinsq[kr] + sqc);
-        if (kr == 0 && kc == 0) st->meanU = (double)h / (double)C::N;  // ortho DC term = sum(U)/N
+        if (pbase + t == 0) h00 = h;  // (compile-time test) lane 0 holds kr = 0 at position 0
       } else if constexpr (MODE == MODE_FWD_NATIVE) {
         hcol[hp] = y[t];
       } else if constexpr (MODE == MODE_FWD_NATURAL) {
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     if constexpr (MODE == MODE_STEP) asm volatile("" : "+v"(e2));  // do not postpone the 2E energy terms
   });
   if constexpr (MODE == MODE_STEP) {
+    if (l == 0 && kc == 0) st->meanU = (double)h00 / (double)C::N;  // ortho DC term = sum(U)/N (solver.py:223)
     const double tot = block_sum(e2, red);
     if (threadIdx.x == 0) partE2[ct] = tot;
   }

@@ -161,5 +161,7 @@ __device__ __forceinline__ T chs_spectral(T hatU, T hatMu, double li, double lj,
   const double CHeig = 1.0 + (lam2 * leig) * leig;
   const double Seig = lam1 * leig;
   const double rhs = (double)hatU + Seig * (double)hatMu;
-  return (T)(rhs / CHeig);
+  // CHeig >= 1: reciprocal + two Newton steps + residual correction (error < 1 ulp of the
+  // correctly rounded quotient, measured) instead of the ~2x longer IEEE division sequence
+  return (T)chs_div_pos(rhs, CHeig);
 }
