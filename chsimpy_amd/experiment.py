@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Monte-Carlo ensemble over (A0, A1) factors: the multi-GPU face of the hot path.
+
+Counterpart of ``chsimpy/experiment.py``.  The reference spreads independent runs over a
+``multiprocessing.Pool`` (experiment.py:197-216); here the runs are dealt to the GPUs of a
+node -- one process per GPU (``torch.distributed``), ``run_id -> rank = run_id mod world`` --
+and every run executes the device-resident timestep loop.  A single N x N grid does not
+shard, so there is no data-path collective: the only communication is one gather of the
+per-run scalar records (12 numbers per run, experiment.py:114-126) at the end, over RCCL
+when the ranks sit on GPUs (backend "nccl") and over gloo in the CPU tests.
+
+The per-run factors depend on ``A_seed`` and ``run_id`` only (experiment.py:148-170), so the
+results do not depend on how many ranks share the work.
+
+    python -m torch.distributed.run --nproc-per-node 8 -m chsimpy_amd.experiment -R 64 -N 2048 -n 2000
+"""
+import argparse
+import os
+
+import numpy as np
+
+from . import utils
+from .parameters import Parameters
+
+COLS = ['A0', 'A1', 'ca', 'cb', 'sa', 'sb', 'tau0', 't0', 'tsep', 'id', 'fac_A0', 'fac_A1']  # experiment.py:218
+
+
+class ExperimentParams:
+    """experiment.py:22-30"""
+
+    def __init__(self):
+        self.runs = 2
+        self.jitter_Arellow = 0.995
+        self.jitter_Arelhigh = 1.005
+        self.processes = -1
+        self.independent = False
+        self.A_source = 'uniform'
+        self.A_seed = 85972
+
+
+def make_rand_values(ep: ExperimentParams):
+    """(rand_values, A_list, runs): the factor table of experiment.py:148-190."""
+    A_list = None
+    rand_values = None
+    if ep.A_source in ('uniform', 'sobol'):
+        if ep.A_source == 'sobol':
+            from scipy.stats import qmc
+            qrng = qmc.Sobol(d=2, seed=ep.A_seed)
+            m = int(np.ceil(np.log2(ep.runs)))
+            rtemp = qrng.random_base2(m)
+            rtemp = qmc.scale(rtemp, ep.jitter_Arellow, ep.jitter_Arelhigh)
+            rtemp = np.transpose(rtemp[:ep.runs])
+        else:
+            rng = np.random.Generator(np.random.PCG64(ep.A_seed))
+            rtemp = rng.uniform(ep.jitter_Arellow, ep.jitter_Arelhigh, size=(ep.runs, 2))
+            rtemp = np.transpose(rtemp)
+        if ep.independent:  # first A0 varies, then A1
+            rand_values = np.ones((2 * ep.runs, 2))
+            rand_values[:ep.runs, 0] = rtemp[0]
+            rand_values[ep.runs:, 1] = rtemp[1]
+        else:
+            rand_values = np.ones((ep.runs, 2))
+            rand_values[:, 0] = rtemp[0]
+            rand_values[:, 1] = rtemp[1]
+    elif ep.A_source == 'grid':
+        nx = int(np.floor(np.sqrt(ep.runs)))
+        ep.runs = nx * nx
+        xvec = np.linspace(ep.jitter_Arellow, ep.jitter_Arelhigh, nx)
+        if ep.independent:
+            rand_values = np.ones((2 * nx, 2))
+            rand_values[:nx, 0] = xvec
+            rand_values[nx:, 1] = xvec
+        else:
+            pts = np.array([[v, w] for v in xvec for w in xvec])
+            rand_values = np.ones((ep.runs, 2))
+            rand_values[:, 0] = pts[:, 0]
+            rand_values[:, 1] = pts[:, 1]
+    else:
+        A_list = utils.csv_import_matrix(ep.A_source)
+    nr_items = rand_values.shape[0] if A_list is None else A_list.shape[0]
+    if ep.independent and ep.A_source in ('sobol', 'uniform'):
+        nr_items = min(2 * ep.runs, nr_items)
+    else:
+        nr_items = min(ep.runs, nr_items)
+    return rand_values, A_list, nr_items
+
+
+def run_params(init_params: Parameters, run_id, rand_values, A_list):
+    """Per-run Parameters with scaled A0/A1 (experiment.py:87-101)."""
+    params = init_params.deepcopy()
+    params.seed = init_params.seed
+    params.file_id = f"{init_params.file_id}-run{run_id}"
+    if A_list is None:
+        fac_A0 = float(rand_values[run_id, 0])
+        fac_A1 = float(rand_values[run_id, 1])
+        params.func_A0 = lambda temp, f=fac_A0: utils.A0(temp) * f
+        params.func_A1 = lambda temp, f=fac_A1: utils.A1(temp) * f
+    else:
+        a0, a1 = float(A_list[run_id][0]), float(A_list[run_id][1])
+        params.func_A0 = lambda temp, a=a0: a
+        params.func_A1 = lambda temp, a=a1: a
+        fac_A0 = fac_A1 = None
+    return params, fac_A0, fac_A1
+
+
+def run_experiment_gpu(run_id, init_params, rand_values, A_list, U_init=None, postprocess=True):
+    """One ensemble member on this rank's GPU; the 12-tuple of experiment.py:114-126."""
+    from .simulator import Simulator
+    params, fac_A0, fac_A1 = run_params(init_params, run_id, rand_values, A_list)
+    simulator = Simulator(params, U_init)
+    solution = simulator.solve()
+    simulator.export()
+    ca = cb = sa = sb = float('nan')
+    if postprocess:
+        try:
+            cgap = utils.get_miscibility_gap(params.R, params.temp, params.B, solution.A0, solution.A1)
+            ca, cb = float(cgap[0]), float(cgap[1])
+            roots = utils.get_roots_of_EPP(params.R, params.temp, solution.A0, solution.A1)
+            sa, sb = float(roots[0]), float(roots[1])
+        except Exception:  # sympy missing or no two roots: keep NaN, the run itself is valid
+            pass
+    itargmax = int(np.argmax(solution.E2))
+    simulator.solver.close()
+    return (solution.A0, solution.A1, ca, cb, sa, sb, solution.tau0, solution.t0, itargmax, run_id,
+            np.nan if fac_A0 is None else fac_A0, np.nan if fac_A1 is None else fac_A1)
+
+
+def my_run_ids(nr_items, rank, world):
+    """run_id -> rank (run_id mod world)."""
+    return [i for i in range(nr_items) if i % world == rank]
+
+
+def gather_records(local, nr_items, rank, world, dist=None, device='cpu'):
+    """All per-run records on every rank, ordered by run id.  One all_gather of a
+    (ceil(n/world), 12) float64 block per rank -- a few KiB; latency-bound, bandwidth irrelevant."""
+    if world == 1 or dist is None:
+        return sorted(local, key=lambda r: r[9])
+    import torch
+    per = (nr_items + world - 1) // world
+    buf = torch.full((per, len(COLS)), float('nan'), dtype=torch.float64, device=device)
+    for i, rec in enumerate(local):
+        buf[i] = torch.tensor([float(x) for x in rec], dtype=torch.float64, device=device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    recs = []
+    for t in out:
+        for row in t.cpu().numpy():
+            if not np.isnan(row[9]):
+                recs.append(tuple(row.tolist()))
+    return sorted(recs, key=lambda r: r[9])
+
+
+def write_results(file_id, records):
+    """``<file_id>-results.csv`` and ``-results-agg.csv`` exactly as experiment.py:218-225."""
+    import pandas as pd
+    df = pd.DataFrame(records, columns=COLS)
+    df[['tau0', 'id']] = df[['tau0', 'id']].astype(int)
+    df.to_csv(f"{file_id}-results.csv")
+    agg = df.loc[:, df.columns != 'id'].describe()
+    agg.loc['cv'] = agg.loc['std'] / agg.loc['mean']
+    agg.T.to_csv(f"{file_id}-results-agg.csv")
+    return df, agg
+
+
+def run_ensemble(init_params, ep, run_fn=None, U_init=None, dist=None, rank=0, world=1, device='cpu'):
+    """Deal the runs to the ranks, execute, gather.  ``run_fn(run_id, init_params, rand_values,
+    A_list)`` defaults to the GPU run; the CPU tests inject a stand-in."""
+    rand_values, A_list, nr_items = make_rand_values(ep)
+    if run_fn is None:
+        def run_fn(run_id, p, rv, al):
+            return run_experiment_gpu(run_id, p, rv, al, U_init)
+    local = [run_fn(i, init_params, rand_values, A_list) for i in my_run_ids(nr_items, rank, world)]
+    return gather_records(local, nr_items, rank, world, dist, device)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='chsimpy_amd ensemble (cf. chsimpy-experiment)')
+    ap.add_argument('-N', type=int, default=512)
+    ap.add_argument('-n', '--ntmax', type=int, default=int(1e6))
+    ap.add_argument('-R', '--runs', type=int, default=3)
+    ap.add_argument('--independent', action='store_true')
+    ap.add_argument('--A-source', default='uniform')
+    ap.add_argument('--A-seed', type=int, default=85972)
+    ap.add_argument('-K', '--kappa-tilde', type=float, default=None)
+    ap.add_argument('--full-sim', action='store_true')
+    ap.add_argument('--file-id', default='auto')
+    ap.add_argument('--export-csv', default=None)
+    ap.add_argument('--Uinit-file', default=None)
+    a = ap.parse_args(argv)
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    device = 'cpu'
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        device = f'cuda:{local_rank}'
+
+    p = Parameters()
+    p.N, p.ntmax, p.full_sim, p.kappa_tilde = a.N, a.ntmax, a.full_sim, a.kappa_tilde
+    p.no_gui, p.export_csv, p.Uinit_file = True, a.export_csv, a.Uinit_file
+    p.device = local_rank
+    p.file_id = utils.get_or_create_file_id(a.file_id)
+    ep = ExperimentParams()
+    ep.runs, ep.independent, ep.A_source, ep.A_seed = a.runs, a.independent, a.A_source, a.A_seed
+    U_init = utils.csv_import_matrix(p.Uinit_file) if p.Uinit_file else None
+
+    records = run_ensemble(p, ep, U_init=U_init, dist=dist, rank=rank, world=world, device=device)
+    if rank == 0:
+        df, agg = write_results(p.file_id, records)
+        print(agg.T)
+        print('Output files:')
+        print(f"  {p.file_id}-results-agg.csv")
+        print(f"  {p.file_id}-results.csv")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -243,3 +243,27 @@ def test_simulator_export_csv(gpu, tmp_path):
     assert np.array_equal(utils.csv_import_matrix(base + '.U.csv'), sol.U)
     assert np.array_equal(utils.csv_import_matrix(base + '.E2.csv'), sol.E2)
     assert utils.csv_import_matrix(base + '.E.csv').shape == (10,)
+
+
+def test_ensemble_members_on_gpu(gpu, tmp_path):
+    """Two Monte-Carlo members (experiment.py:84-126) through the GPU path vs the oracle with
+    the same scaled A0/A1."""
+    from chsimpy_amd import experiment as ex, utils
+    p = make(128, 40)
+    p.file_id = str(tmp_path / 'ens')
+    ep = ex.ExperimentParams()
+    ep.runs = 2
+    recs = ex.run_ensemble(p, ep)
+    rv, _, n = ex.make_rand_values(ep)
+    assert n == 2 and len(recs) == 2
+    for i, rec in enumerate(recs):
+        f0, f1 = rv[i]
+        o = orc.OracleSolver(orc.make_params(128, 40, func_A0=lambda T, f=f0: orc.A0(T) * f,
+                                             func_A1=lambda T, f=f1: orc.A1(T) * f))
+        o.prepare()
+        o.solve_or_resume()
+        assert rec[0] == pytest.approx(o.A0, rel=1e-15) and rec[1] == pytest.approx(o.A1, rel=1e-15)
+        assert rec[8] == int(np.argmax(o.timedata.data()[:, 2])) and rec[9] == i
+        assert rec[10] == f0 and rec[11] == f1
+    df, agg = ex.write_results(p.file_id, recs)
+    assert os.path.exists(p.file_id + '-results.csv')
