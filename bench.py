@@ -75,8 +75,8 @@ def cpu_baseline(N, steps_hint):
     from threadpoolctl import threadpool_limits
     from oracle import chs_oracle as orc
     with threadpool_limits(limits=1, user_api='blas'):
-        # size the sample: ~0.3 us per grid point per step on one core
-        est = 0.45e-6 * N * N
+        # size the sample: ~0.09 us per grid point per step (measured on the GPU box host) on one core
+        est = 0.09e-6 * N * N
         steps = steps_hint or int(max(2, min(200, 20.0 / est)))
         p = orc.make_params(N, steps + 1)
         o = orc.OracleSolver(p)
