@@ -28,7 +28,23 @@ enum { MODE_STEP = 0, MODE_FWD_NATIVE = 1, MODE_FWD_NATURAL = 2, MODE_INV_NATURA
 
 template <class C>
 __device__ __forceinline__ size_t tile_addr(int r, int k) {
-  return ((size_t)(k / C::C) * C::N + r) * C::C + (k % C::C);
+  return ((size_t)(k / C::CT) * C::N + r) * C::CT + (k % C::CT);
+}
+
+// First row of a row-kernel workgroup.  CT consecutive rows share 128-byte lines of T1/T2; when
+// a workgroup holds fewer rows (C < CT) the CT/C workgroups of one line group are given block
+// numbers b, b+8, b+16, ... : workgroups are dealt round-robin over the 8 XCDs, so these land on
+// one XCD (one L2) and are dispatched back to back -- a speed matter only, never correctness.
+template <class C>
+__device__ __forceinline__ int row_of_block(int b) {
+  constexpr int Q = C::CT / C::C;
+  if constexpr (Q == 1) {
+    return b * C::C;
+  } else {
+    const int xcd = b & 7, j = b >> 3;
+    const int g = xcd + 8 * (j / Q), m = j % Q;
+    return g * C::CT + m * C::C;
+  }
 }
 
 template <typename T>
@@ -54,6 +70,47 @@ __device__ __forceinline__ void store4(T* p, const T q[4]) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 
+// Start-up stagger (experiment knob): every second workgroup of an XCD sleeps for
+// CHS_STAGGER x ~3.5 us before its first load, so that the memory phase of one half overlaps the
+// compute phase of the other (a kernel here has only 2-4 rounds of workgroups: no steady state).
+#ifndef CHS_STAGGER_ROW
+#define CHS_STAGGER_ROW 0
+#endif
+#ifndef CHS_STAGGER_COL
+#define CHS_STAGGER_COL 0
+#endif
+template <int NSLEEP>
+__device__ __forceinline__ void stagger_start() {
+  if constexpr (NSLEEP > 0) {
+    if ((blockIdx.x >> 3) & 1) {
+#pragma unroll 1
+      for (int i = 0; i < NSLEEP; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+}
+
+// ---- diagnostic build only (-DCHS_STAMPS): s_memtime stamps at the phase boundaries of the
+// row and column kernels, first wave of every workgroup; read back with chs_debug_stamps().
+// The stamp values go to a buffer nothing else reads; no output is computed from them.
+#ifdef CHS_STAMPS
+#define CHS_NSTAMP 12
+__device__ unsigned long long g_stamps[2][8192 * CHS_NSTAMP];
+#define STAMP(K, I)                                                                         \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    unsigned long long t__;                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[K][blockIdx.x * CHS_NSTAMP + (I)] = t__; \
+  } while (0)
+extern "C" int chs_debug_stamps(int which, unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n,
+                                  sizeof(unsigned long long) * 8192 * CHS_NSTAMP * which);
+}
+#else
+#define STAMP(K, I) do {} while (0)
+#endif
+
 // Returns x through an opaque asm so that index arithmetic derived from it is not CSE'd
 // with (and kept alive since) an earlier phase of the kernel: recomputing a few integer
 // offsets is far cheaper than holding dozens of address registers across a phase.
@@ -76,7 +133,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
-  const int row = blockIdx.x * C::C + sub;
+  const int row = row_of_block<C>(blockIdx.x) + sub;
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
   double s2 = 0.0;
@@ -139,14 +196,19 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
-  const int row = blockIdx.x * C::C + sub;
+  if constexpr (DIAG && FUSE) stagger_start<CHS_STAGGER_ROW>();
+  const int row0 = row_of_block<C>(blockIdx.x);
+  const int row = row0 + sub;
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
+  if constexpr (DIAG && FUSE) STAMP(0, 0);
   recombine<C, false, true>(re, im, tb, l, [&](int, const int idx[4], T y[4]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) y[t] = T2[tile_addr<C>(row, idx[t])];
   });
+  if constexpr (DIAG && FUSE) STAMP(0, 1);
   inv_passes<C>(re, im, scr, tb, launder(l));
+  if constexpr (DIAG && FUSE) STAMP(0, 2);
   __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
   T* urow = U + (size_t)row * C::N;
   double sEdge = 0.0;
@@ -174,14 +236,16 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       }
     }
   }
+  if constexpr (DIAG && FUSE) STAMP(0, 3);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (DIAG) {
     // Row-edge terms of np.gradient (rows 0/1 and N-2/N-1) and Ra of row int(N/2)+1
     // (solver.py:226-227): only the two or three workgroups that own those rows take this
     // block-uniform branch; the neighbour row is read back from HBM behind the barrier.
     constexpr int RR = C::N / 2 + 1;
-    const bool first_blk = (blockIdx.x == 0), last_blk = (blockIdx.x == gridDim.x - 1);
-    const bool ra_blk = (blockIdx.x == RR / C::C);
+    static_assert(C::C >= 2, "rows 0/1 and N-2/N-1 must share a workgroup");
+    const bool first_blk = (row0 == 0), last_blk = (row0 == C::N - C::C);
+    const bool ra_blk = (row0 == (RR / C::C) * C::C);
     if (first_blk || last_blk || ra_blk) {
       __syncthreads();  // this workgroup's rows are in memory and visible to its other waves
       const bool e0 = first_blk && sub == 0, e1 = last_blk && sub == C::C - 1;
@@ -250,15 +314,18 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     }
     acc[0] = sE; acc[1] = sEdge; acc[2] = sPS; acc[3] = cSA; acc[4] = s2;
   }
+  if constexpr (DIAG && FUSE) STAMP(0, 4);
   if constexpr (FUSE) {
     __builtin_amdgcn_sched_barrier(0);
     fwd_passes<C>(re, im, scr, tb, launder(l));
+    if constexpr (DIAG && FUSE) STAMP(0, 5);
     __builtin_amdgcn_sched_barrier(0);
     recombine<C, true, false>(re, im, tb, launder(l), [&](int, const int idx[4], T y[4]) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
     });
   }
+  if constexpr (DIAG && FUSE) STAMP(0, 6);
   if constexpr (DIAG) {
     // reductions last: the transform registers are dead by now
     double out5[5];
@@ -281,6 +348,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
 // ---------------------------------------------------------------------------
 template <class C>
 struct ColStage {
+  static_assert(C::C == C::CT, "k_col works on whole tiles");
   static constexpr int LINE = 4 * C::C;        // elements per 4-row line of the tile
   static constexpr int LP = LINE + 1;          // padded line pitch in LDS (conflict-free quad reads)
   static constexpr int LINES = C::M / 4;       // lines per round
@@ -305,6 +373,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   using CS = ColStage<C>;
   __shared__ double red[32];
   if (st->halt) return;
+  if constexpr (MODE == MODE_STEP) stagger_start<CHS_STAGGER_COL>();
+  if constexpr (MODE == MODE_STEP) STAMP(1, 0);
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
   const int ct = blockIdx.x;
@@ -360,14 +430,16 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       }
     }
     __syncthreads();
+    if constexpr (MODE == MODE_STEP) STAMP(1, 1);
     fwd_passes<C>(re, im, scr, tb, l);
+    if constexpr (MODE == MODE_STEP) STAMP(1, 2);
   }
 
   // ---- recombination / spectral stage / adjoint recombination, in place per slot
   T* hcol = hat + (size_t)kc * C::N;
   const double lam1 = st->lam1, lam2 = st->lam2;
   const double lc = lam[kc];
-  const double sqc = (MODE == MODE_STEP) ? sinsq[kc] : 0.0;
+  const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc + 1] : 0.0;
   double e2 = 0.0;
   T h00 = T(0);
   constexpr bool FWD = (MODE != MODE_INV_NATURAL);
@@ -378,10 +450,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       const int kr = idx[t];
       const size_t hp = (size_t)(pbase + t) * C::G + l;
       if constexpr (MODE == MODE_STEP) {
-        const T h = chs_spectral<T>(hcol[hp], y[t], lam[kr], lc, lam1, lam2);
+        const double2 ls = reinterpret_cast<const double2*>(sinsq)[kr];  // {lambda_kr, sin^2(pi kr/N)}
+        const T h = chs_spectral<T>(hcol[hp], y[t], ls.x, lc, lam1, lam2);
         hcol[hp] = h;
         y[t] = h;
-        e2 += (double)h * (double)h * (sinsq[kr] + sqc);
+        e2 += (double)h * (double)h * (ls.y + sqc);
         if (pbase + t == 0) h00 = h;  // (compile-time test) lane 0 holds kr = 0 at position 0
       } else if constexpr (MODE == MODE_FWD_NATIVE) {
         hcol[hp] = y[t];
@@ -393,14 +466,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     }
     if constexpr (MODE == MODE_STEP) asm volatile("" : "+v"(e2));  // do not postpone the 2E energy terms
   });
+  if constexpr (MODE == MODE_STEP) STAMP(1, 5);
   if constexpr (MODE == MODE_STEP) {
     if (l == 0 && kc == 0) st->meanU = (double)h00 / (double)C::N;  // ortho DC term = sum(U)/N (solver.py:223)
-    const double tot = block_sum(e2, red);
-    if (threadIdx.x == 0) partE2[ct] = tot;
   }
-
+  if constexpr (MODE == MODE_STEP) STAMP(1, 3);
   if constexpr (ADJ) {
     inv_passes<C>(re, im, scr, tb, l);
+    if constexpr (MODE == MODE_STEP) STAMP(1, 4);
     // ---- stage out: quads -> tile rows
     T* tile = Tout + (size_t)ct * C::N * C::C;
 #pragma unroll
@@ -431,6 +504,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       }
     }
   }
+  if constexpr (MODE == MODE_STEP) {
+    // the tile's share of the spectral gradient sum, last (registers are free, one barrier)
+    const double acc1[1] = {e2};
+    double tot1[1];
+    block_sum_store<1, C::THREADS / 64>(acc1, red, tot1);
+    if (threadIdx.x == 0) partE2[ct] = tot1[0];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -439,7 +519,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
 enum { ROW_INV_PLAIN = 0, ROW_INV_DIAG = 1, ROW_INV_FUSED = 2 };
 
 struct FastPlan {
-  int N, G, R0, RA, RB, RL, threads;
+  int N, G, R0, RA, RB, RL, threads, col_tiles;
   void* tables = nullptr;  // one device allocation
   size_t off_tw0, off_twa, off_twb, off_wp, off_t1, off_t2;  // element offsets
   int (*row_fwd)(Engine*, const void*, void*, bool) = nullptr;
@@ -463,7 +543,7 @@ struct Launch {
   using T = typename C::T;
   static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T);
   static constexpr size_t col_lds = (size_t)col_lds_elems<CC>() * sizeof(T);
-  static_assert(C::N == CC::N && C::C == CC::C && C::THREADS == CC::THREADS, "row/column configs must agree on the tile layout");
+  static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
 
   template <class K>
   static int set_lds(K kernel, size_t bytes) {
@@ -511,20 +591,20 @@ struct Launch {
     return CHS_OK;
   }
   static int col(Engine* E, int mode, const void* tin, void* tout, void* hat, void* nat) {
-    const int grid = C::N / C::C;
+    const int grid = CC::N / CC::C;
     const FTables<T> tb = get_tables<T>(E);
     switch (mode) {
       case MODE_STEP:
-        k_col<CC, MODE_STEP><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_STEP><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       case MODE_FWD_NATIVE:
-        k_col<CC, MODE_FWD_NATIVE><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_FWD_NATIVE><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       case MODE_FWD_NATURAL:
-        k_col<CC, MODE_FWD_NATURAL><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_FWD_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
       default:
-        k_col<CC, MODE_INV_NATURAL><<<grid, C::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_INV_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
         break;
     }
     CHS_HIP(hipGetLastError());
@@ -542,17 +622,22 @@ using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 #ifndef CHS_ROW_WPS
 #define CHS_ROW_WPS 4
 #endif
-using F4096 = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, CHS_ROW_WPS>;
+#ifndef CHS_ROW_THREADS
+#define CHS_ROW_THREADS 512
+#endif
+// row kernels: CHS_ROW_THREADS/128 rows per workgroup, tiles of 4 columns
+using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS_ROW_WPS, 4>;
 // k_col runs best with the full register file of two waves per SIMD (no spills; the compiler
 // uses the room to keep more loads in flight): measured 305 -> 191 us per launch
 #ifndef CHS_COL_WPS
 #define CHS_COL_WPS 2
 #endif
-using F4096C = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS>;  // k_col register budget
+using F4096C = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS, 4>;  // k_col: whole tiles
 
 template <class C, class CC = C>
 static void bind(FastPlan* P) {
   P->N = C::N; P->G = C::G; P->R0 = C::R0; P->RA = C::RA; P->RB = C::RB; P->RL = C::RL; P->threads = C::THREADS;
+  P->col_tiles = CC::N / CC::C;
   P->row_fwd = &Launch<C, CC>::row_fwd;
   P->row_inv = &Launch<C, CC>::row_inv;
   P->col = &Launch<C, CC>::col;
@@ -615,11 +700,17 @@ static int build_tables(Engine* E, FastPlan* P) {
   for (int kk = 0; kk <= M; ++kk) { long double r, i; Tk(M - kk, r, i); push(r, -i); }
   CHS_HIP(hipMalloc(&P->tables, h.size() * sizeof(T)));
   CHS_HIP(hipMemcpy(P->tables, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-  // sin^2(pi k/N): weights of the spectral form of np.gradient's sum of squares
-  std::vector<double> sq(N);
-  for (int k = 0; k < N; ++k) { const long double v = sinl(PI * (long double)k / (long double)N); sq[k] = (double)(v * v); }
-  CHS_HIP(hipMalloc(&E->dSinSq, sizeof(double) * N));
-  CHS_HIP(hipMemcpy(E->dSinSq, sq.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+  // interleaved {lambda_k, sin^2(pi k/N)}: the eigenvalue table of utils.py:35 next to the weights of
+  // the spectral form of np.gradient's sum of squares -- one 16-byte load per coefficient
+  std::vector<double> lam(N), sq(2 * (size_t)N);
+  CHS_HIP(hipMemcpy(lam.data(), E->dLambda, sizeof(double) * N, hipMemcpyDeviceToHost));
+  for (int k = 0; k < N; ++k) {
+    const long double v = sinl(PI * (long double)k / (long double)N);
+    sq[2 * k] = lam[k];
+    sq[2 * k + 1] = (double)(v * v);
+  }
+  CHS_HIP(hipMalloc(&E->dSinSq, sizeof(double) * 2 * N));
+  CHS_HIP(hipMemcpy(E->dSinSq, sq.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice));
   return CHS_OK;
 }
 
@@ -641,7 +732,7 @@ int chs_fast_init(Engine* E) {
   // the row kernels write one partial record per workgroup, k_col one per column tile
   E->nRowBlocks = E->N / (P->threads / P->G);
   E->nPartMu = E->nRowBlocks;
-  E->nPartE2 = E->nRowBlocks;
+  E->nPartE2 = P->col_tiles;
   CHS_HIP(hipMalloc(&E->dPartE2, sizeof(double) * (size_t)E->nPartE2));
   CHS_HIP(hipMalloc(&E->dPartRa, sizeof(double) * 8));
   return CHS_OK;

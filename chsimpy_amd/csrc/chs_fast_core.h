@@ -22,7 +22,7 @@
 // compile-time configuration
 // ---------------------------------------------------------------------------
 template <typename T_, int N_, int G_, int THREADS_, int R0_, int RA_, int RB_, int RL_, int PAD1_, int PAD2_,
-          int PADL_, int WPS_>
+          int PADL_, int WPS_, int CT_ = THREADS_ / G_>
 struct FCfg {
   using T = T_;
   static constexpr int N = N_;
@@ -45,6 +45,8 @@ struct FCfg {
   static constexpr int NP2 = E / (2 * RL_);  // mirror pairs per lane, last pass
   static constexpr int THREADS = THREADS_;
   static constexpr int C = THREADS_ / G_;    // transforms per workgroup
+  static constexpr int CT = CT_;             // columns per tile of the T1/T2 layout (k_col needs C == CT)
+  static_assert(CT_ % (THREADS_ / G_) == 0, "a tile must hold whole workgroups");
   static constexpr int WPS = WPS_;           // waves per SIMD the kernels are compiled for
   static constexpr int P1 = L1 + PAD1_;      // pitch of X1[kappa < S1][m < L1]
   static constexpr int P2 = L2 + PAD2_;      // pitch of X2[kappa < S2A][m < L2]
@@ -251,16 +253,26 @@ struct Own {
 // ---------------------------------------------------------------------------
 // recombination slot and its adjoint (tools/dct_model.py: slot_fwd / slot_adj)
 // ---------------------------------------------------------------------------
+// the three recombination twiddles of one slot
 template <typename T>
-__device__ __forceinline__ void slot_fwd(T Ar, T Ai, T Zr, T Zi, const FTables<T>& tb, int kk, T& y0, T& y1, T& y2,
-                                         T& y3) {
+struct SlotTw {
+  T wr, wi, ar, ai, br, bi;
+};
+template <typename T>
+__device__ __forceinline__ SlotTw<T> slot_tw(const FTables<T>& tb, int kk) {
+  SlotTw<T> w;
+  ldc(tb.wp, kk, w.wr, w.wi);
+  ldc(tb.t1, kk, w.ar, w.ai);
+  ldc(tb.t2, kk, w.br, w.bi);
+  return w;
+}
+
+template <typename T>
+__device__ __forceinline__ void slot_fwd(T Ar, T Ai, T Zr, T Zi, const SlotTw<T>& w, T& y0, T& y1, T& y2, T& y3) {
   // B = conj(Z2); P = A + B; D = A - B
   const T Pr = Ar + Zr, Pi = Ai - Zi;
   T Dr = Ar - Zr, Di = Ai + Zi;
-  T wr, wi, ar, ai, br, bi;
-  ldc(tb.wp, kk, wr, wi);
-  ldc(tb.t1, kk, ar, ai);
-  ldc(tb.t2, kk, br, bi);
+  const T wr = w.wr, wi = w.wi, ar = w.ar, ai = w.ai, br = w.br, bi = w.bi;
   cmul<T, false>(Dr, Di, wr, wi);  // Q = w' D
   const T S1r = Pr + Dr, S1i = Pi + Di;
   const T S2r = Pr - Dr, S2i = Pi - Di;
@@ -271,12 +283,8 @@ __device__ __forceinline__ void slot_fwd(T Ar, T Ai, T Zr, T Zi, const FTables<T
 }
 
 template <typename T>
-__device__ __forceinline__ void slot_adj(T y0, T y1, T y2, T y3, const FTables<T>& tb, int kk, T& gAr, T& gAi, T& gZr,
-                                         T& gZi) {
-  T wr, wi, ar, ai, br, bi;
-  ldc(tb.wp, kk, wr, wi);
-  ldc(tb.t1, kk, ar, ai);
-  ldc(tb.t2, kk, br, bi);
+__device__ __forceinline__ void slot_adj(T y0, T y1, T y2, T y3, const SlotTw<T>& w, T& gAr, T& gAi, T& gZr, T& gZi) {
+  const T wr = w.wr, wi = w.wi, ar = w.ar, ai = w.ai, br = w.br, bi = w.bi;
   // gS1 = conj(T1 * (y0 + i y1));  gS2 = conj(T2) * (y2 + i y3)
   const T g1r = ar * y0 - ai * y1, g1i = -(ar * y1 + ai * y0);
   const T g2r = br * y2 + bi * y3, g2i = br * y3 - bi * y2;
@@ -534,50 +542,54 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
         const int kk = k1 + C::S2 * k;
+        const SlotTw<T> w = slot_tw<T>(tb, kk);  // shared by the forward and the adjoint half
         T y[4] = {T(0), T(0), T(0), T(0)};
-        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k], tb, kk, y[0], y[1], y[2], y[3]);
+        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k], w, y[0], y[1], y[2], y[3]);
         const int idx[4] = {kk, N - kk, M - kk, M + kk};
         f((q * R2 + k) * 4, idx, y);
-        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], tb, kk, r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
+        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], w, r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
       }
     } else {
       // butterfly 0 pairs with itself (k <-> R2-k), butterfly S2/2 with itself (k <-> R2-1-k);
       // position 0 holds (X[0], X[M/2], X[M], X[3M/2]) from the two self-paired outputs
       {
+        const SlotTw<T> w0 = slot_tw<T>(tb, 0), wh = slot_tw<T>(tb, M / 2);
         T y[4] = {T(0), T(0), T(0), T(0)};
         if constexpr (FWD) {
           T a0, a1, a2, a3, b0, b1, b2, b3;
-          slot_fwd<T>(r1[0], i1[0], r1[0], i1[0], tb, 0, a0, a1, a2, a3);
-          slot_fwd<T>(r1[R2 / 2], i1[R2 / 2], r1[R2 / 2], i1[R2 / 2], tb, M / 2, b0, b1, b2, b3);
+          slot_fwd<T>(r1[0], i1[0], r1[0], i1[0], w0, a0, a1, a2, a3);
+          slot_fwd<T>(r1[R2 / 2], i1[R2 / 2], r1[R2 / 2], i1[R2 / 2], wh, b0, b1, b2, b3);
           y[0] = a0; y[1] = b0; y[2] = a2; y[3] = b1;
         }
         const int idx[4] = {0, M / 2, M, 3 * (M / 2)};
         f(q * R2 * 4, idx, y);
         if constexpr (ADJ) {
           T gar, gai, gzr, gzi;
-          slot_adj<T>(y[0], T(0), y[2], T(0), tb, 0, gar, gai, gzr, gzi);
+          slot_adj<T>(y[0], T(0), y[2], T(0), w0, gar, gai, gzr, gzi);
           r1[0] = gar + gzr; i1[0] = gai + gzi;
-          slot_adj<T>(y[1], y[3], T(0), T(0), tb, M / 2, gar, gai, gzr, gzi);
+          slot_adj<T>(y[1], y[3], T(0), T(0), wh, gar, gai, gzr, gzi);
           r1[R2 / 2] = gar + gzr; i1[R2 / 2] = gai + gzi;
         }
       }
 #pragma unroll
       for (int k = 1; k < R2 / 2; ++k) {
         const int kk = C::S2 * k;
+        const SlotTw<T> w = slot_tw<T>(tb, kk);
         T y[4] = {T(0), T(0), T(0), T(0)};
-        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r1[R2 - k], i1[R2 - k], tb, kk, y[0], y[1], y[2], y[3]);
+        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r1[R2 - k], i1[R2 - k], w, y[0], y[1], y[2], y[3]);
         const int idx[4] = {kk, N - kk, M - kk, M + kk};
         f((q * R2 + k) * 4, idx, y);
-        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], tb, kk, r1[k], i1[k], r1[R2 - k], i1[R2 - k]);
+        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], w, r1[k], i1[k], r1[R2 - k], i1[R2 - k]);
       }
 #pragma unroll
       for (int k = 0; k < R2 / 2; ++k) {
         const int kk = C::S2 / 2 + C::S2 * k;
+        const SlotTw<T> w = slot_tw<T>(tb, kk);
         T y[4] = {T(0), T(0), T(0), T(0)};
-        if constexpr (FWD) slot_fwd<T>(r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k], tb, kk, y[0], y[1], y[2], y[3]);
+        if constexpr (FWD) slot_fwd<T>(r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k], w, y[0], y[1], y[2], y[3]);
         const int idx[4] = {kk, N - kk, M - kk, M + kk};
         f((q * R2 + R2 / 2 + k) * 4, idx, y);
-        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], tb, kk, r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
+        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], w, r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
       }
     }
   }
