@@ -634,6 +634,13 @@ using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS
 #endif
 using F4096C = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS, 4>;  // k_col: whole tiles
 
+// fp32 configurations (BASELINE.json configs[3]: N = 8192 fp32): 32 complex values per lane
+// occupy the same 64 VGPRs as 16 fp64 ones; reductions and the spectral update stay in fp64.
+using G8192 = FCfg<float, 8192, 128, 512, 16, 4, 4, 16, 2, 1, 16, 4, 4>;
+using G8192C = FCfg<float, 8192, 128, 512, 16, 4, 4, 16, 2, 1, 16, 2, 4>;
+using G4096 = FCfg<float, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 4, 4>;
+using G4096C = FCfg<float, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 2, 4>;
+
 template <class C, class CC = C>
 static void bind(FastPlan* P) {
   P->N = C::N; P->G = C::G; P->R0 = C::R0; P->RA = C::RA; P->RB = C::RB; P->RL = C::RL; P->threads = C::THREADS;
@@ -645,7 +652,7 @@ static void bind(FastPlan* P) {
 }
 
 bool chs_fast_supported(int N, int dtype) {
-  if (dtype != CHS_F64) return false;
+  if (dtype == CHS_F32) return N == 4096 || N == 8192;
   return N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096;
 }
 
@@ -716,6 +723,13 @@ static int build_tables(Engine* E, FastPlan* P) {
 
 int chs_fast_init(Engine* E) {
   FastPlan* P = new FastPlan();
+  if (E->dtype == CHS_F32) {
+    switch (E->N) {
+      case 4096: bind<G4096, G4096C>(P); break;
+      case 8192: bind<G8192, G8192C>(P); break;
+      default: delete P; chs_set_error("fast engine (fp32): unsupported N"); return CHS_EINVAL;
+    }
+  } else
   switch (E->N) {
     case 128: bind<F128>(P); break;
     case 256: bind<F256>(P); break;
@@ -726,7 +740,7 @@ int chs_fast_init(Engine* E) {
     default: delete P; chs_set_error("fast engine: unsupported N"); return CHS_EINVAL;
   }
   E->dTw = P;
-  int rc = build_tables<double>(E, P);
+  int rc = (E->dtype == CHS_F32) ? build_tables<float>(E, P) : build_tables<double>(E, P);
   if (rc) return rc;
   if ((rc = P->init(E))) return rc;
   // the row kernels write one partial record per workgroup, k_col one per column tile

@@ -267,3 +267,77 @@ def test_ensemble_members_on_gpu(gpu, tmp_path):
         assert rec[10] == f0 and rec[11] == f1
     df, agg = ex.write_results(p.file_id, recs)
     assert os.path.exists(p.file_id + '-results.csv')
+
+
+# ---------------------------------------------------------------------------
+# fp32 (BASELINE.json configs[3]: N=8192, fp32, adaptive_time).  The reference is float64 only
+# (numpy defaults everywhere), so fp32 runs are validated against the fp64 path with a stated,
+# looser tolerance: per-step U within rtol 2e-4 and E within rtol 1e-5 after 560 steps.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_fp32_dctn(gpu, N):
+    p = make(N, 2, 'fast', dtype='float32')
+    s = chsimpy_amd.Solver(p, np.full((N, N), 0.5))
+    eng = s._get_engine()
+    assert eng.engine == 'fast'
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((N, N)).astype(np.float32).astype(np.float64)
+    Y = eng.dctn(X)
+    T = scifft.dct(scifft.dct(X, axis=1, norm='ortho')[:, [0, 5, N - 1]], axis=0, norm='ortho')
+    assert np.max(np.abs(Y[:, [0, 5, N - 1]] - T)) < 2e-5 * np.max(np.abs(T))
+    assert np.sum(Y * Y) == pytest.approx(np.sum(X * X), rel=1e-5)
+    Z = eng.dctn(Y, inverse=True)
+    assert np.max(np.abs(Z - X)) < 2e-5 * np.max(np.abs(X))
+    s.close()
+
+
+def test_fp32_adaptive_vs_fp64_n4096(gpu):
+    # The reference's dynamic step is a column SUM (np.linalg.norm(.., ord=-1), solver.py:183), so it
+    # grows with N: with the default delt_max the step explodes at N=4096 (NaN at step 506, which the
+    # engine reports as the reference would).  delt_max is chosen so that the dynamic step is ~2x delt.
+    nt = 560
+    runs = {}
+    for dt in ('float64', 'float32'):
+        p = make(4096, nt, 'fast', dtype=dt, adaptive_time=True, delt_max=1.2e-10)
+        s = chsimpy_amd.Solver(p)
+        s.prepare()
+        sol = s.solve_or_resume()
+        runs[dt] = (sol.U.copy(), sol.timedata.data().copy())
+        s.close()
+    U64, t64 = runs['float64']
+    U32, t32 = runs['float32']
+    assert t32.shape == t64.shape == (nt, 9)
+    assert len(np.unique(t64[:, 8])) > 3                       # the step size adapts after step 500
+    assert np.allclose(t32[:, 8], t64[:, 8], rtol=2e-3)        # same delt history
+    assert np.allclose(U32, U64, rtol=2e-4, atol=0), relerr(U32, U64)
+    assert np.allclose(t32[:, 1], t64[:, 1], rtol=1e-5)        # E
+    assert np.allclose(t32[:, 7], t64[:, 7], rtol=1e-3)        # PS
+
+
+def test_fp32_n8192_adaptive_runs(gpu):
+    """configs[3] itself: N=8192, fp32, adaptive_time -- size-independent properties."""
+    N = 8192
+    p = make(N, 506, 'fast', dtype='float32', adaptive_time=True, delt_max=6e-11)
+    s = chsimpy_amd.Solver(p)
+    s.prepare()
+    sol = s.solve_or_resume()
+    td = sol.timedata.data()
+    assert td.shape == (506, 9) and not np.any(np.isnan(td))
+    assert len(np.unique(td[:, 8])) >= 3                        # adaptive dt fired (steps 502, 504)
+    assert sol.U.mean() == pytest.approx(s.U_init.mean(), rel=2e-6)   # mass conservation in fp32
+    assert 0.8 < sol.U.min() and sol.U.max() < 0.95
+    assert np.all(td[501:, 8] >= td[500, 8])                    # the step only grows here
+    s.close()
+
+
+def test_adaptive_default_delt_max_blows_up_at_large_n_like_the_reference_quirk(gpu):
+    """delt_dyn = min column SUM scales with N: at N=4096 the default
+    delt_max makes the step jump by ~800x at step 502 and U leaves (0,1) -> the NaN assertion."""
+    p = make(4096, 520, 'fast', adaptive_time=True)
+    s = chsimpy_amd.Solver(p)
+    s.prepare()
+    with pytest.raises(AssertionError):
+        s.solve_or_resume()
+    assert 502 <= s.solution.computed_steps <= 510
+    assert s.solution.delt[-1] > 1e-6
+    s.close()
