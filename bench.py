@@ -98,11 +98,19 @@ def main():
         a.gpus = world
     dist = None
     import torch
+    # one process per GPU over RCCL (backend "nccl"); CHS_DIST_BACKEND=gloo + CHS_BENCH_SAME_GPU=1 lets the
+    # N>1 logic be rehearsed with several ranks on a single-GPU box (collectives on CPU tensors)
+    backend = os.environ.get('CHS_DIST_BACKEND', 'nccl')
+    same_gpu = os.environ.get('CHS_BENCH_SAME_GPU') == '1'
+    device = 0 if (world == 1 or same_gpu) else local_rank
+    coll_dev = 'cpu' if backend == 'gloo' else f'cuda:{device}'
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-    device = local_rank if world > 1 else 0
+        torch.cuda.set_device(device)
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', device))
+        else:
+            dist.init_process_group(backend=backend)
 
     import __graft_entry__ as g
     if rank == 0:
@@ -138,11 +146,11 @@ def main():
     dt = t1 - t0
     dev_ms = eng.last_step_ms()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # the ensemble's only collective: gather the per-run energy scalars (E, E2 of the last step)
-        mine = torch.tensor([float(rows[-1, 1]), float(rows[-1, 2])], dtype=torch.float64, device='cuda')
+        mine = torch.tensor([float(rows[-1, 1]), float(rows[-1, 2])], dtype=torch.float64, device=coll_dev)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         energies = [[float(v[0]), float(v[1])] for v in allv]
