@@ -82,7 +82,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 template <int NSLEEP>
 __device__ __forceinline__ void stagger_start() {
   if constexpr (NSLEEP > 0) {
-    if ((blockIdx.x >> 3) & 1) {
+    // blocks b and b + 256 are the two residents of one CU (8 XCDs x 32 CUs, dealt round-robin)
+    if ((blockIdx.x >> 8) & 1) {
 #pragma unroll 1
       for (int i = 0; i < NSLEEP; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -288,14 +289,18 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     const T RT = (T)dc.RT, BRT = (T)dc.BRT, B = (T)dc.B, A0 = (T)dc.A0, A1 = (T)dc.A1;
     const double mean = st->meanU, thr = dc.threshold;
     double sE = 0.0, sPS = 0.0, cSA = 0.0, s2 = 0.0;
+    // One domain check per grid point (numpy: log of a non-positive number is NaN / -inf, which
+    // the reference turns into its NaN assertion, timedata.py:10): the sums are poisoned at the end.
+    int bad = 0;
     auto point = [&](T& u) {
       const T uinv = T(1) - u;
-      const T lU = chs_log<T>(u), lV = chs_log<T>(uinv);
-      sE += (double)chs_energy_from_logs<T>(u, uinv, lU, lV, RT, B, A0, A1);
+      bad |= ((u > T(0)) && (uinv > T(0))) ? 0 : 1;
+      const T lU = chs_log_pos<T>(u), lV = chs_log_pos<T>(uinv);
+      sE += (double)chs_energy_from_logs_fast<T>(u, uinv, lU, lV, RT, B, A0, A1);
       sPS += fabs((double)u - mean);
       cSA += ((double)u < thr) ? 1.0 : 0.0;
       if constexpr (FUSE) {
-        const T m = chs_mu_from_logs<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
+        const T m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
         s2 += (double)m * (double)m;
         u = m;
         // opaque use: finishes this grid point before the next one starts, so the
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       }
       // ... and the running sums: otherwise the compiler postpones all 2E energy terms
       // (keeping log U, log(1-U), 1-U of every point alive) to add them up at the end
-      asm volatile("" : "+v"(sE), "+v"(sPS), "+v"(cSA));
+      asm volatile("" : "+v"(sE), "+v"(sPS), "+v"(cSA), "+v"(bad));
     };
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
@@ -312,6 +317,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       point(im[e]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (bad) sE = __builtin_nan("");  // U left (0,1): the record of this step becomes NaN
     acc[0] = sE; acc[1] = sEdge; acc[2] = sPS; acc[3] = cSA; acc[4] = s2;
   }
   if constexpr (DIAG && FUSE) STAMP(0, 4);

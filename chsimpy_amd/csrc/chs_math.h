@@ -33,6 +33,17 @@ __device__ __forceinline__ double chs_div_pos(double d, double sig) {
   return __builtin_fma(rho, r, q);
 }
 
+// The same quotient with ONE Newton step: the residual correction squares whatever error the
+// reciprocal still has (2^-14 would already do), so the result is as accurate as chs_div_pos.
+__device__ __forceinline__ double chs_div_pos1(double d, double sig) {
+  double r = __builtin_amdgcn_rcp(sig);
+  const double e = __builtin_fma(-sig, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = d * r;
+  const double rho = __builtin_fma(-sig, q, d);
+  return __builtin_fma(rho, r, q);
+}
+
 // s -> 2 atanh(s) for |s| <= 0.1716
 __device__ __forceinline__ double chs_log_poly(double s) {
   const double z = s * s;
@@ -66,6 +77,20 @@ __device__ __forceinline__ double chs_log_f64(double x) {
   return res;
 }
 
+// log(x) for x known to be positive and finite (the caller checks the domain once per grid
+// point instead of three selects per logarithm)
+__device__ __forceinline__ double chs_log_pos_f64(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const int c = (m < CHS_SQRT1_2) ? 1 : 0;
+  m = __builtin_ldexp(m, c);                  // [sqrt(1/2), sqrt(2))
+  e -= c;
+  const double s = chs_div_pos1(m - 1.0, m + 1.0);
+  const double lq = chs_log_poly(s);
+  const double k = (double)e;
+  return __builtin_fma(k, CHS_LN2_HI, __builtin_fma(k, CHS_LN2_LO, lq));
+}
+
 // log(a / b) without forming the quotient
 __device__ __forceinline__ double chs_log_ratio_f64(double a, double b) {
   double ma = __builtin_amdgcn_frexp_mant(a), mb = __builtin_amdgcn_frexp_mant(b);  // [0.5, 1)
@@ -85,6 +110,10 @@ __device__ __forceinline__ double chs_log_ratio_f64(double a, double b) {
   const bool ok = (a > 0.0) && (b > 0.0) && (a < __builtin_inf()) && (b < __builtin_inf());
   return ok ? res : __builtin_nan("");  // every non-finite case ends in the NaN assertion anyway
 }
+
+template <typename T> __device__ __forceinline__ T chs_log_pos(T x);
+template <> __device__ __forceinline__ double chs_log_pos<double>(double x) { return chs_log_pos_f64(x); }
+template <> __device__ __forceinline__ float chs_log_pos<float>(float x) { return logf(x); }
 
 template <typename T> __device__ __forceinline__ T chs_log(T x);
 template <> __device__ __forceinline__ double chs_log<double>(double x) { return chs_log_f64(x); }
@@ -135,6 +164,24 @@ __device__ __forceinline__ T chs_energy_from_logs(T U, T Uinv, T lU, T lV, T RT,
 template <typename T>
 __device__ __forceinline__ T chs_mu_from_logs(T U, T Uinv, T lU, T lV, T RT, T BRT, T A0, T A1) {
 #pragma clang fp contract(off)
+  const T U2inv = Uinv - U;
+  const T t1 = RT * (lU - lV);
+  const T t2 = (A0 + A1 * U2inv) * U2inv;
+  const T t3 = ((T(2) * A1) * U) * Uinv;
+  return ((t1 - BRT) + t2) - t3;
+}
+
+// Fused-kernel variants: same expressions, the compiler may contract a*b+c into one fma (each
+// contraction removes a rounding; the results move by < 1 ulp, far inside the 1e-9 tolerance).
+template <typename T>
+__device__ __forceinline__ T chs_energy_from_logs_fast(T U, T Uinv, T lU, T lV, T RT, T B, T A0, T A1) {
+  const T a = U * (lU - B);
+  const T b = Uinv * lV;
+  const T c = ((A0 + A1 * (Uinv - U)) * U) * Uinv;
+  return RT * (a + b) + c;
+}
+template <typename T>
+__device__ __forceinline__ T chs_mu_from_logs_fast(T U, T Uinv, T lU, T lV, T RT, T BRT, T A0, T A1) {
   const T U2inv = Uinv - U;
   const T t1 = RT * (lU - lV);
   const T t2 = (A0 + A1 * U2inv) * U2inv;

@@ -28,6 +28,17 @@ def test_log_accuracy(gpu):
     assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and np.isnan(sp[3])
 
 
+def test_log_pos_accuracy(gpu):
+    rng = np.random.default_rng(4)
+    x = np.concatenate([rng.random(300000), 1 - rng.random(100000) * 1e-3, np.exp(rng.uniform(-700, 700, 100000)),
+                        np.linspace(0.70, 0.72, 50001), np.linspace(0.999, 1.001, 50001)])
+    x = x[x > 0]
+    got = _lib.test_math(4, x)
+    ref = np.log(np.asarray(x, dtype=np.longdouble)).astype(np.float64)
+    ok = ref != 0
+    assert ulp_err(got[ok], ref[ok]).max() <= 2.5
+
+
 def test_log_ratio_accuracy(gpu):
     rng = np.random.default_rng(1)
     U = np.concatenate([rng.uniform(0.5, 1 - 1e-9, 300000), rng.uniform(1e-9, 0.5, 300000),
