@@ -162,14 +162,25 @@ def write_results(file_id, records):
     return df, agg
 
 
-def run_ensemble(init_params, ep, run_fn=None, U_init=None, dist=None, rank=0, world=1, device='cpu'):
+def run_ensemble(init_params, ep, run_fn=None, U_init=None, dist=None, rank=0, world=1, device='cpu',
+                 concurrent=1):
     """Deal the runs to the ranks, execute, gather.  ``run_fn(run_id, init_params, rand_values,
-    A_list)`` defaults to the GPU run; the CPU tests inject a stand-in."""
+    A_list)`` defaults to the GPU run; the CPU tests inject a stand-in.
+
+    ``concurrent`` members of a rank run at the same time (one engine handle = one HIP stream each;
+    the C ABI calls release the GIL): at ensemble sizes such as N=2048 a single run leaves the GPU
+    partly idle between its latency-bound kernels, two or three concurrent runs fill the gaps."""
     rand_values, A_list, nr_items = make_rand_values(ep)
     if run_fn is None:
         def run_fn(run_id, p, rv, al):
             return run_experiment_gpu(run_id, p, rv, al, U_init)
-    local = [run_fn(i, init_params, rand_values, A_list) for i in my_run_ids(nr_items, rank, world)]
+    ids = my_run_ids(nr_items, rank, world)
+    if concurrent > 1 and len(ids) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=concurrent) as pool:
+            local = list(pool.map(lambda i: run_fn(i, init_params, rand_values, A_list), ids))
+    else:
+        local = [run_fn(i, init_params, rand_values, A_list) for i in ids]
     return gather_records(local, nr_items, rank, world, dist, device)
 
 
@@ -186,6 +197,7 @@ def main(argv=None):
     ap.add_argument('--file-id', default='auto')
     ap.add_argument('--export-csv', default=None)
     ap.add_argument('--Uinit-file', default=None)
+    ap.add_argument('--concurrent', type=int, default=2, help='ensemble members running at once per GPU')
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get('RANK', '0'))
@@ -209,7 +221,8 @@ def main(argv=None):
     ep.runs, ep.independent, ep.A_source, ep.A_seed = a.runs, a.independent, a.A_source, a.A_seed
     U_init = utils.csv_import_matrix(p.Uinit_file) if p.Uinit_file else None
 
-    records = run_ensemble(p, ep, U_init=U_init, dist=dist, rank=rank, world=world, device=device)
+    records = run_ensemble(p, ep, U_init=U_init, dist=dist, rank=rank, world=world, device=device,
+                           concurrent=a.concurrent)
     if rank == 0:
         df, agg = write_results(p.file_id, records)
         print(agg.T)
