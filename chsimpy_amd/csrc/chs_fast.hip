@@ -755,6 +755,17 @@ int chs_fast_init(Engine* E) {
   E->nPartE2 = P->col_tiles;
   CHS_HIP(hipMalloc(&E->dPartE2, sizeof(double) * (size_t)E->nPartE2));
   CHS_HIP(hipMalloc(&E->dPartRa, sizeof(double) * 8));
+  // second set of partial sums + side stream for the overlapped tail (chs_fast_step)
+  E->partSet[0][0] = E->dPartDiag; E->partSet[0][1] = E->dPartMu; E->partSet[0][2] = E->dPartE2; E->partSet[0][3] = E->dPartRa;
+  CHS_HIP(hipMalloc(&E->partSet[1][0], sizeof(double) * 4 * (size_t)(E->nDiagBlocks > E->N ? E->nDiagBlocks : E->N)));
+  CHS_HIP(hipMalloc(&E->partSet[1][1], sizeof(double) * (size_t)(E->nBands > E->N ? E->nBands : E->N)));
+  CHS_HIP(hipMalloc(&E->partSet[1][2], sizeof(double) * (size_t)E->nPartE2));
+  CHS_HIP(hipMalloc(&E->partSet[1][3], sizeof(double) * 8));
+  CHS_HIP(hipStreamCreateWithFlags(&E->stream2, hipStreamNonBlocking));
+  for (int q = 0; q < 2; ++q) {
+    CHS_HIP(hipEventCreateWithFlags(&E->evRow[q], hipEventDisableTiming));
+    CHS_HIP(hipEventCreateWithFlags(&E->evTail[q], hipEventDisableTiming));
+  }
   return CHS_OK;
 }
 
@@ -763,9 +774,22 @@ void chs_fast_free(Engine* E) {
   if (!P) return;
   if (P->tables) hipFree(P->tables);
   if (E->dSinSq) hipFree(E->dSinSq);
+  // the "current" pointers alias one of the two sets: hand set 0 back to the generic owners
+  if (E->partSet[0][0]) {
+    E->dPartDiag = E->partSet[0][0]; E->dPartMu = E->partSet[0][1];
+    E->dPartE2 = E->partSet[0][2]; E->dPartRa = E->partSet[0][3];
+    for (int i = 0; i < 4; ++i) { hipFree(E->partSet[1][i]); E->partSet[1][i] = nullptr; E->partSet[0][i] = nullptr; }
+  }
   if (E->dPartE2) hipFree(E->dPartE2);
   if (E->dPartRa) hipFree(E->dPartRa);
   E->dPartRa = nullptr;
+  for (int q = 0; q < 2; ++q) {
+    if (E->evRow[q]) hipEventDestroy(E->evRow[q]);
+    if (E->evTail[q]) hipEventDestroy(E->evTail[q]);
+    E->evRow[q] = E->evTail[q] = nullptr;
+  }
+  if (E->stream2) hipStreamDestroy(E->stream2);
+  E->stream2 = nullptr;
   E->dSinSq = nullptr; E->dPartE2 = nullptr;
   delete P;
   E->dTw = nullptr;
@@ -792,8 +816,17 @@ int chs_fast_enter(Engine* E) {
 
 // T1 <- row DCT-II of EnergieEut(U): what the fused row kernel of the previous step would
 // have left behind; needed once per solve_or_resume call.
+// the set of partial-sum buffers the kernels of the running step write to
+static void select_partial_set(Engine* E) {
+  if (!E->partSet[0][0]) return;
+  const int par = E->parity;
+  E->dPartDiag = E->partSet[par][0]; E->dPartMu = E->partSet[par][1];
+  E->dPartE2 = E->partSet[par][2]; E->dPartRa = E->partSet[par][3];
+}
+
 int chs_fast_prologue(Engine* E) {
   FastPlan* P = (FastPlan*)E->dTw;
+  select_partial_set(E);  // sum(mu^2) must land where the first step's k_pre looks for it
   chs_slot_begin(E, SLOT_MU);
   const int rc = P->row_fwd(E, E->dU, E->dT1, true);
   chs_slot_end(E, SLOT_MU);
@@ -804,11 +837,30 @@ int chs_fast_prologue(Engine* E) {
 // EnergieEut(U_k) and partMu its sum of squares; on exit U_(k+1) is in HBM, the pointwise
 // diagnostics partials of U_(k+1) are ready for k_fin and, with fuse_next, T1/partMu are
 // ready for the next step.
+// Nothing k_step_tail decides can gate the next step when the time step is fixed, the energy rule
+// only records (full_sim) and there is no time limit: then the tail of step s may run on a second
+// stream next to k_col of step s+1 (NaN still halts everything, one step later at most).
+static bool can_overlap_tail(const Engine* E) {
+  return !E->dc.adaptive_time && E->dc.full_sim && !(E->dc.time_limit_s > 0.0) && !E->timer.on &&
+         E->stream2 != nullptr;
+}
+
 int chs_fast_step(Engine* E, bool first, bool last) {
   FastPlan* P = (FastPlan*)E->dTw;
   int rc;
+  const bool overlap = can_overlap_tail(E);
+  const int par = E->parity;
+  if (overlap) {
+    // partial sums ping-pong between two sets; the set is free once the tail that read it is done
+    if (E->tailPending[par]) {
+      CHS_HIP(hipStreamWaitEvent(E->stream, E->evTail[par], 0));
+      E->tailPending[par] = false;
+    }
+  }
+  select_partial_set(E);
   if (first) {
-    // time-step control of the first step of the call; later steps get it from k_step_tail
+    // time-step control of the first step of the call; later steps get it from k_step_tail.
+    // The prologue wrote sum(mu^2) into the set that was current then: fold it in here.
     if (E->dc.adaptive_time) {
       if ((rc = chs_launch_mu_colsums(E, 0))) return rc;
     }
@@ -827,7 +879,22 @@ int chs_fast_step(Engine* E, bool first, bool last) {
     // this step has not advanced computed_steps yet, hence the offset
     if ((rc = chs_launch_mu_colsums(E, 1))) return rc;
   }
-  return chs_launch_step_tail(E, last ? 0 : 1);
+  if (!overlap) return chs_launch_step_tail(E, last ? 0 : 1, E->stream);
+  CHS_HIP(hipEventRecord(E->evRow[par], E->stream));
+  CHS_HIP(hipStreamWaitEvent(E->stream2, E->evRow[par], 0));
+  if ((rc = chs_launch_step_tail(E, last ? 0 : 1, E->stream2))) return rc;
+  CHS_HIP(hipEventRecord(E->evTail[par], E->stream2));
+  E->tailPending[par] = true;
+  E->parity ^= 1;
+  if (last) {
+    // the call ends here: the main stream joins the side stream
+    for (int q = 0; q < 2; ++q)
+      if (E->tailPending[q]) {
+        CHS_HIP(hipStreamWaitEvent(E->stream, E->evTail[q], 0));
+        E->tailPending[q] = false;
+      }
+  }
+  return CHS_OK;
 }
 
 // Jitter path (solver.py:210-211 perturbs U between the inverse transform and the record):

@@ -395,17 +395,24 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_step_tail(const T* __restrict_
     DevState loc = *st;
     fin_update(dc, &loc, E, E2, tot[2] / N2, tot[3] / N2, Ra, rows, rowsCap);
     if (do_pre && !loc.halt) pre_update(dc, &loc, tot[5], adapt, tot[NV]);
-    *st = loc;
+    // write back everything except meanU: in the overlapped pipeline k_col of the NEXT step may be
+    // storing it at this very moment (it is the only other writer of the state)
+    st->delt = loc.delt; st->time_delta_sum = loc.time_delta_sum; st->time_passed = loc.time_passed;
+    st->tau0 = loc.tau0; st->t0 = loc.t0; st->E2_0 = loc.E2_0; st->E2_prev = loc.E2_prev;
+    st->L2_cur = loc.L2_cur; st->lam1 = loc.lam1; st->lam2 = loc.lam2;
+    st->computed_steps = loc.computed_steps; st->rows_written = loc.rows_written;
+    st->skip_check = loc.skip_check; st->stop_reason = loc.stop_reason; st->nan_flag = loc.nan_flag;
+    st->halt = loc.halt;
   }
 }
 
-int chs_launch_step_tail(Engine* E, int do_pre) {
+int chs_launch_step_tail(Engine* E, int do_pre, hipStream_t stream) {
   chs_slot_begin(E, SLOT_FIN);
   DISPATCH_T(E,
-    (k_step_tail<double><<<1, TAIL_THREADS, 0, E->stream>>>((const double*)E->dU, E->dc, E->dState, E->dPartDiag,
+    (k_step_tail<double><<<1, TAIL_THREADS, 0, stream>>>((const double*)E->dU, E->dc, E->dState, E->dPartDiag,
         E->nRowBlocks, E->dPartE2, E->nPartE2, E->dPartMu, E->nPartMu, E->dPartColMin, E->nColMinBlocks, E->dPartRa,
         E->dRows, E->rowsCap, do_pre)),
-    (k_step_tail<float><<<1, TAIL_THREADS, 0, E->stream>>>((const float*)E->dU, E->dc, E->dState, E->dPartDiag,
+    (k_step_tail<float><<<1, TAIL_THREADS, 0, stream>>>((const float*)E->dU, E->dc, E->dState, E->dPartDiag,
         E->nRowBlocks, E->dPartE2, E->nPartE2, E->dPartMu, E->nPartMu, E->dPartColMin, E->nColMinBlocks, E->dPartRa,
         E->dRows, E->rowsCap, do_pre)));
   chs_slot_end(E, SLOT_FIN);
