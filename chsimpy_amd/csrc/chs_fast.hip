@@ -354,14 +354,28 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
 // ---------------------------------------------------------------------------
 template <class C>
 struct ColStage {
-  static_assert(C::C == C::CT, "k_col works on whole tiles");
-  static constexpr int LINE = 4 * C::C;        // elements per 4-row line of the tile
+  // A workgroup stages C of the CT columns of a tile: per row a piece of C elements at offset
+  // h*C inside the row's CT elements (C == CT: the whole, contiguous tile).
+  static constexpr int LINE = 4 * C::C;        // elements of one staged 4-row line in LDS
   static constexpr int LP = LINE + 1;          // padded line pitch in LDS (conflict-free quad reads)
-  static constexpr int LINES = C::M / 4;       // lines per round
+  static constexpr int LINES = C::M / 4;       // lines per round (N/2 rows)
+  static constexpr int ROWS = C::N / 2;        // rows per round
   static constexpr int ELEMS = LINES * LP;     // staging elements
   static constexpr int JR = C::R0 / 4;         // pass-0 half-indices j per round
+  static constexpr int PER = ROWS * C::C / (2 * C::THREADS);  // 16-byte (2-element) pieces per thread per round
+  static constexpr int Q = C::CT / C::C;       // workgroups per tile
   static_assert(C::R0 >= 4, "pass-0 radix must be >= 4");
-  static_assert((LINES * LINE) % (2 * C::THREADS) == 0, "the tile must split evenly over the threads");
+  static_assert(C::C % 2 == 0, "pieces are moved two elements at a time");
+  static_assert((ROWS * C::C) % (2 * C::THREADS) == 0, "the tile must split evenly over the threads");
+  // global element offset (inside the tile) and LDS offset of piece f = 2*(tid + i*THREADS) of round rho
+  static __device__ __forceinline__ size_t goff(int rho, int f, int h) {
+    const int row = f / C::C, c = f % C::C;
+    return ((size_t)rho * ROWS + row) * C::CT + h * C::C + c;
+  }
+  static __device__ __forceinline__ int loff(int f) {
+    const int row = f / C::C, c = f % C::C;
+    return (row / 4) * LP + (row % 4) * C::C + c;
+  }
 };
 
 template <class C>
@@ -383,27 +397,35 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   if constexpr (MODE == MODE_STEP) STAMP(1, 0);
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
-  const int ct = blockIdx.x;
-  const int kc = ct * C::C + sub;  // this group's column
+  // tile and the part of it this workgroup owns; the Q workgroups of a tile get block numbers
+  // b, b+8, ...: same XCD under round-robin dispatch (speed only, see row_of_block)
+  int ct, hh;
+  if constexpr (CS::Q == 1) {
+    ct = blockIdx.x; hh = 0;
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    ct = xcd + 8 * (j / CS::Q); hh = j % CS::Q;
+  }
+  const int kc = ct * C::CT + hh * C::C + sub;  // this group's column
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
   if constexpr (MODE != MODE_INV_NATURAL) {
     // ---- stage in: tile rows -> quads of this group's column.  The whole tile is requested
     // first (one HBM latency for both rounds), then it passes through LDS half by half.
-    const T* tile = Tin + (size_t)ct * C::N * C::C;
-    constexpr int PER = CS::LINES * CS::LINE / (2 * C::THREADS);  // 16-byte loads per thread per round
+    const T* tile = Tin + (size_t)ct * C::N * C::CT;
+    constexpr int PER = CS::PER;
     T stage[2][2 * PER];
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
-      const T* src = tile + (size_t)rho * CS::LINES * CS::LINE;
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int f = 2 * (threadIdx.x + i * C::THREADS);
+        const T* src = tile + CS::goff(rho, f, hh);
         if constexpr (sizeof(T) == 8) {
-          const double2 v = *reinterpret_cast<const double2*>(src + f);
+          const double2 v = *reinterpret_cast<const double2*>(src);
           stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
         } else {
-          const float2 v = *reinterpret_cast<const float2*>(src + f);
+          const float2 v = *reinterpret_cast<const float2*>(src);
           stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
         }
       }
@@ -414,9 +436,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int f = 2 * (threadIdx.x + i * C::THREADS);
-        const int line = f / CS::LINE, off = f % CS::LINE;
-        lds[line * CS::LP + off] = stage[rho][2 * i];
-        lds[line * CS::LP + off + 1] = stage[rho][2 * i + 1];
+        const int lo = CS::loff(f);
+        lds[lo] = stage[rho][2 * i];
+        lds[lo + 1] = stage[rho][2 * i + 1];
       }
       __syncthreads();
 #pragma unroll
@@ -481,7 +503,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     inv_passes<C>(re, im, scr, tb, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 4);
     // ---- stage out: quads -> tile rows
-    T* tile = Tout + (size_t)ct * C::N * C::C;
+    T* tile = Tout + (size_t)ct * C::N * C::CT;
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
       __syncthreads();
@@ -501,12 +523,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         }
       }
       __syncthreads();
-      T* dst = tile + (size_t)rho * CS::LINES * CS::LINE;
-      for (int f = 2 * threadIdx.x; f < CS::LINES * CS::LINE; f += 2 * C::THREADS) {
-        const int line = f / CS::LINE, off = f % CS::LINE;
-        const T a = lds[line * CS::LP + off], b = lds[line * CS::LP + off + 1];
-        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst + f) = make_double2(a, b);
-        else *reinterpret_cast<float2*>(dst + f) = make_float2(a, b);
+#pragma unroll
+      for (int i = 0; i < CS::PER; ++i) {
+        const int f = 2 * (threadIdx.x + i * C::THREADS);
+        const int lo = CS::loff(f);
+        T* dst = tile + CS::goff(rho, f, hh);
+        const T a = lds[lo], b = lds[lo + 1];
+        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(a, b);
+        else *reinterpret_cast<float2*>(dst) = make_float2(a, b);
       }
     }
   }
@@ -515,7 +539,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     const double acc1[1] = {e2};
     double tot1[1];
     block_sum_store<1, C::THREADS / 64>(acc1, red, tot1);
-    if (threadIdx.x == 0) partE2[ct] = tot1[0];
+    if (threadIdx.x == 0) partE2[blockIdx.x] = tot1[0];
   }
 }
 
@@ -638,7 +662,11 @@ using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS
 #ifndef CHS_COL_WPS
 #define CHS_COL_WPS 2
 #endif
-using F4096C = FCfg<double, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS, 4>;  // k_col: whole tiles
+#ifndef CHS_COL_THREADS
+#define CHS_COL_THREADS 256
+#endif
+// k_col: CHS_COL_THREADS/128 of the 4 columns of a tile per workgroup
+using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS, 4>;
 
 // fp32 configurations (BASELINE.json configs[3]: N = 8192 fp32): 32 complex values per lane
 // occupy the same 64 VGPRs as 16 fp64 ones; reductions and the spectral update stay in fp64.

@@ -19,7 +19,7 @@ lib = _lib.load()
 lib.chs_debug_stamps.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
 names = {0: ['recombine^T (T2 loads)', 'inv passes', 'store U', 'pointwise (+edges)', 'fwd passes', 'recombine (T1 stores)'],
          1: ['stage in (tile loads)', 'fwd passes', 'spectral (hat r/w)', 'inv passes', 'stage out']}
-for which, nblk in ((0, 1024), (1, 1024)):
+for which, nblk in ((0, 1024), (1, 2048)):
     buf = np.zeros(8192 * NST, dtype=np.uint64)
     rc = lib.chs_debug_stamps(which, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size)
     st = buf.reshape(8192, NST)[:nblk].astype(np.int64)
