@@ -103,6 +103,7 @@ __device__ unsigned long long g_stamps[2][8192 * CHS_NSTAMP];
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
     __builtin_amdgcn_sched_barrier(0);                                                      \
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[K][blockIdx.x * CHS_NSTAMP + (I)] = t__; \
+    if ((K) == 1 && threadIdx.x == 64 && blockIdx.x < 8192) g_stamps[K][blockIdx.x * CHS_NSTAMP + (I) + 6] = t__; \
   } while (0)
 extern "C" int chs_debug_stamps(int which, unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n,
@@ -160,10 +161,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
     }
   }
   fwd_passes<C>(re, im, scr, tb, l);
-  recombine<C, true, false>(re, im, tb, l, [&](int, const int idx[4], T y[4]) {
+  recombine<C, true, false, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
+                            [&](int, const int idx[4], T y[4], bool live, NoFetch) {
+    if (live) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
-  });
+      for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
+    }
+  }, [](int, const int*, T*, bool) {});
   if constexpr (POINTWISE) {
     const double tot = block_sum(s2, red);
     if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
@@ -203,10 +207,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
   if constexpr (DIAG && FUSE) STAMP(0, 0);
-  recombine<C, false, true>(re, im, tb, l, [&](int, const int idx[4], T y[4]) {
+  recombine<C, false, true, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
+                            [&](int, const int idx[4], T y[4], bool, NoFetch) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) y[t] = T2[tile_addr<C>(row, idx[t])];
-  });
+  }, [](int, const int*, T*, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
   inv_passes<C>(re, im, scr, tb, launder(l));
   if constexpr (DIAG && FUSE) STAMP(0, 2);
@@ -326,10 +331,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     fwd_passes<C>(re, im, scr, tb, launder(l));
     if constexpr (DIAG && FUSE) STAMP(0, 5);
     __builtin_amdgcn_sched_barrier(0);
-    recombine<C, true, false>(re, im, tb, launder(l), [&](int, const int idx[4], T y[4]) {
+    recombine<C, true, false, false>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
+                              [&](int, const int idx[4], T y[4], bool live, NoFetch) {
+      if (live) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
-    });
+        for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
+      }
+    }, [](int, const int*, T*, bool) {});
   }
   if constexpr (DIAG && FUSE) STAMP(0, 6);
   if constexpr (DIAG) {
@@ -472,28 +480,54 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   T h00 = T(0);
   constexpr bool FWD = (MODE != MODE_INV_NATURAL);
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL);
-  recombine<C, FWD, ADJ>(re, im, tb, l, [&](int pbase, const int idx[4], T y[4]) {
+  if constexpr (MODE == MODE_STEP) {
+    struct Fetched { T h[4]; double2 ls[4]; };
+    recombine<C, true, true, true>(re, im, tb, l,
+      [&](int pbase, const int idx[4]) {
+        Fetched p;
+        const T* hl = hcol + fc_opaque(l);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int kr = idx[t];
-      const size_t hp = (size_t)(pbase + t) * C::G + l;
-      if constexpr (MODE == MODE_STEP) {
-        const double2 ls = reinterpret_cast<const double2*>(sinsq)[kr];  // {lambda_kr, sin^2(pi kr/N)}
-        const T h = chs_spectral<T>(hcol[hp], y[t], ls.x, lc, lam1, lam2);
-        hcol[hp] = h;
-        y[t] = h;
-        e2 += (double)h * (double)h * (ls.y + sqc);
-        if (pbase + t == 0) h00 = h;  // (compile-time test) lane 0 holds kr = 0 at position 0
-      } else if constexpr (MODE == MODE_FWD_NATIVE) {
-        hcol[hp] = y[t];
-      } else if constexpr (MODE == MODE_FWD_NATURAL) {
-        nat[(size_t)kr * C::N + kc] = y[t];
-      } else {
-        y[t] = nat[(size_t)kr * C::N + kc];
+        for (int t = 0; t < 4; ++t) {
+          p.h[t] = hl[(size_t)(pbase + t) * C::G];
+          p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];  // {lambda_kr, sin^2(pi kr/N)}
+        }
+        return p;
+      },
+      [&](int pbase, const int*, T y[4], bool live, const Fetched& p) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const T h = chs_spectral<T>(p.h[t], y[t], p.ls[t].x, lc, lam1, lam2);
+          y[t] = h;
+          const double term = (double)h * (double)h * (p.ls[t].y + sqc);
+          e2 += live ? term : 0.0;
+          if (pbase + t == 0 && live) h00 = h;  // lane 0 holds kr = 0 at position 0 (its own slot)
+        }
+        asm volatile("" : "+v"(e2));  // do not postpone the 2E energy terms
+      },
+      [&](int pbase, const int*, T y[4], bool live) {
+        if (live) {
+          T* hl = hcol + fc_opaque(l);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) hl[(size_t)(pbase + t) * C::G] = y[t];
+        }
+      });
+  } else {
+    recombine<C, FWD, ADJ, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
+                           [&](int pbase, const int idx[4], T y[4], bool live, NoFetch) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int kr = idx[t];
+        const size_t hp = (size_t)(pbase + t) * C::G + l;
+        if constexpr (MODE == MODE_FWD_NATIVE) {
+          if (live) hcol[hp] = y[t];
+        } else if constexpr (MODE == MODE_FWD_NATURAL) {
+          if (live) nat[(size_t)kr * C::N + kc] = y[t];
+        } else {
+          y[t] = nat[(size_t)kr * C::N + kc];
+        }
       }
-    }
-    if constexpr (MODE == MODE_STEP) asm volatile("" : "+v"(e2));  // do not postpone the 2E energy terms
-  });
+    }, [](int, const int*, T*, bool) {});
+  }
   if constexpr (MODE == MODE_STEP) STAMP(1, 5);
   if constexpr (MODE == MODE_STEP) {
     if (l == 0 && kc == 0) st->meanU = (double)h00 / (double)C::N;  // ortho DC term = sum(U)/N (solver.py:223)
@@ -525,7 +559,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < CS::PER; ++i) {
-        const int f = 2 * (threadIdx.x + i * C::THREADS);
+        // laundered: the staging addresses are recomputed here instead of being kept alive in
+        // registers since the stage-in (a spill reload here would wait on every hat_U store)
+        const int f = 2 * (launder((int)threadIdx.x) + i * C::THREADS);
         const int lo = CS::loff(f);
         T* dst = tile + CS::goff(rho, f, hh);
         const T a = lds[lo], b = lds[lo + 1];

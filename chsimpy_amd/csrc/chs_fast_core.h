@@ -17,6 +17,7 @@
 // tools/dct_model.py is the executable model of these index maps.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 // ---------------------------------------------------------------------------
 // compile-time configuration
@@ -527,69 +528,163 @@ __device__ __forceinline__ void inv_passes(typename C::T* re, typename C::T* im,
 //   ADJ: y[4] -> (gA, gZ) written back over (A, Z) (slot_adj)
 // With FWD only the registers are left untouched; with ADJ only y comes from f.
 // ===========================================================================
-template <class C, bool FWD, bool ADJ, class F>
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
+struct NoFetch {};
+// x through an opaque asm: address arithmetic derived from it is redone at the point of use instead
+// of being computed for all slots up front and kept in registers
+__device__ __forceinline__ int fc_opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// Recombination slots of one lane.  PIPE: the twiddles of slot k+1 and whatever `pre(pbase, idx)`
+// fetches for it (global loads only) are requested after slot k's `f(pbase, idx, y, live, fetched)`
+// has computed its results and before `st(pbase, idx, y, live)` stores them.  A load requested after
+// a store cannot be waited for without waiting for the store too (one in-order vmcnt counter), so
+// without this every slot would sit out the full latency of the previous slot's stores.
+// !PIPE: everything of slot k is fetched in slot k (f may load and store as it likes, st is empty).
+template <class C, bool FWD, bool ADJ, bool PIPE, class PRE, class F, class ST>
 __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, const FTables<typename C::T>& tb,
-                                          int l, F&& f) {
+                                          int l, PRE&& pre, F&& f, ST&& st) {
   using T = typename C::T;
-  constexpr int R2 = C::R2, N = C::N, M = C::M;
+  constexpr int R2 = C::R2, N = C::N, M = C::M, H = R2 / 2;
 #pragma unroll
   for (int q = 0; q < C::NP2; ++q) {
-    int k1, k2; bool sp;
-    Own<C>::last_pair(l, q, k1, k2, sp);
     T* r1 = re + (q * 2 + 0) * R2; T* i1 = im + (q * 2 + 0) * R2;
     T* r2 = re + (q * 2 + 1) * R2; T* i2 = im + (q * 2 + 1) * R2;
-    if (!sp) {
+    const int kap = l + C::G * q;
+    // Only butterfly pair 0 = (0, S2/2) (lane 0, q = 0) pairs its outputs inside its own butterflies.
+    // A wavefront without that lane runs the plain slots; the wavefront holding it runs the same
+    // slots with the special lane's operands selected in (v_cndmask) plus one short slot for the
+    // lane itself -- instead of a second, divergent pass over all slots for a single lane.
+    bool has_special = false;
+    if (q == 0) has_special = (C::G < 64) || (__builtin_amdgcn_readfirstlane(l) < 64);
+    if (!has_special) {
+      SlotTw<T> wn;
+      const int id0[4] = {kap, N - kap, M - kap, M + kap};
+      decltype(pre(0, id0)) pn;
+      if constexpr (PIPE) {
+        wn = slot_tw<T>(tb, kap);
+        pn = pre(q * R2 * 4, id0);
+      }
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
-        const int kk = k1 + C::S2 * k;
-        const SlotTw<T> w = slot_tw<T>(tb, kk);  // shared by the forward and the adjoint half
+        const int kk = kap + C::S2 * k;
+        if (!PIPE) {
+          wn = slot_tw<T>(tb, kk);
+          const int idc[4] = {kk, N - kk, M - kk, M + kk};
+          pn = pre((q * R2 + k) * 4, idc);
+        }
+        const SlotTw<T> w = wn;  // shared by the forward and the adjoint half
+        const auto pc = pn;
         T y[4] = {T(0), T(0), T(0), T(0)};
         if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k], w, y[0], y[1], y[2], y[3]);
         const int idx[4] = {kk, N - kk, M - kk, M + kk};
-        f((q * R2 + k) * 4, idx, y);
+        f((q * R2 + k) * 4, idx, y, true, pc);
+        if (PIPE && k + 1 < R2) {  // requested before this slot's stores
+          const int kn = fc_opaque(kap) + C::S2 * (k + 1);
+          wn = slot_tw<T>(tb, kn);
+          const int idn[4] = {kn, N - kn, M - kn, M + kn};
+          pn = pre((q * R2 + k + 1) * 4, idn);
+        }
+        st((q * R2 + k) * 4, idx, y, true);
         if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], w, r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
       }
     } else {
-      // butterfly 0 pairs with itself (k <-> R2-k), butterfly S2/2 with itself (k <-> R2-1-k);
-      // position 0 holds (X[0], X[M/2], X[M], X[3M/2]) from the two self-paired outputs
-      {
+      const bool sp = (kap == 0);
+      // The special lane: butterfly 0 pairs k <-> R2-k, butterfly S2/2 pairs k <-> R2-1-k.  Its slot
+      // s = 1..H-1 works on (r1[s], r1[R2-s]), slot s = H..R2-1 on (r2[s-H], r2[R2-1-(s-H)]); slot 0
+      // holds (X[0], X[M/2], X[M], X[3M/2]) from the two self-paired outputs r1[0], r1[H].
+      auto sel = [&](T a, T b) { return sp ? a : b; };
+      auto kk_of = [&](int k) {
+        const int kk_s = (k == 0) ? C::S2 : ((k < H) ? C::S2 * k : C::S2 / 2 + C::S2 * (k - H));  // k = 0: unused
+        return sp ? kk_s : kap + C::S2 * k;
+      };
+      const int kk0 = kk_of(0);
+      SlotTw<T> wn;
+      const int id0[4] = {kk0, N - kk0, M - kk0, M + kk0};
+      decltype(pre(0, id0)) pn;
+      if (sp) {
         const SlotTw<T> w0 = slot_tw<T>(tb, 0), wh = slot_tw<T>(tb, M / 2);
+        const int idx[4] = {0, M / 2, M, 3 * (M / 2)};
+        const auto p0 = pre(q * R2 * 4, idx);
         T y[4] = {T(0), T(0), T(0), T(0)};
         if constexpr (FWD) {
           T a0, a1, a2, a3, b0, b1, b2, b3;
           slot_fwd<T>(r1[0], i1[0], r1[0], i1[0], w0, a0, a1, a2, a3);
-          slot_fwd<T>(r1[R2 / 2], i1[R2 / 2], r1[R2 / 2], i1[R2 / 2], wh, b0, b1, b2, b3);
+          slot_fwd<T>(r1[H], i1[H], r1[H], i1[H], wh, b0, b1, b2, b3);
           y[0] = a0; y[1] = b0; y[2] = a2; y[3] = b1;
         }
-        const int idx[4] = {0, M / 2, M, 3 * (M / 2)};
-        f(q * R2 * 4, idx, y);
+        f(q * R2 * 4, idx, y, true, p0);
+        if constexpr (PIPE) {
+          wn = slot_tw<T>(tb, kk0);
+          pn = pre(q * R2 * 4, id0);
+        }
+        st(q * R2 * 4, idx, y, true);
         if constexpr (ADJ) {
           T gar, gai, gzr, gzi;
           slot_adj<T>(y[0], T(0), y[2], T(0), w0, gar, gai, gzr, gzi);
           r1[0] = gar + gzr; i1[0] = gai + gzi;
           slot_adj<T>(y[1], y[3], T(0), T(0), wh, gar, gai, gzr, gzi);
-          r1[R2 / 2] = gar + gzr; i1[R2 / 2] = gai + gzi;
+          r1[H] = gar + gzr; i1[H] = gai + gzi;
         }
+      } else if constexpr (PIPE) {
+        wn = slot_tw<T>(tb, kk0);
+        pn = pre(q * R2 * 4, id0);
       }
 #pragma unroll
-      for (int k = 1; k < R2 / 2; ++k) {
-        const int kk = C::S2 * k;
-        const SlotTw<T> w = slot_tw<T>(tb, kk);
+      for (int k = 0; k < R2; ++k) {
+        const int kk = kk_of(k);
+        if (!PIPE) {
+          wn = slot_tw<T>(tb, kk);
+          const int idc[4] = {kk, N - kk, M - kk, M + kk};
+          pn = pre((q * R2 + k) * 4, idc);
+        }
+        const SlotTw<T> w = wn;
+        const auto pc = pn;
+        // operand registers: *_n for every other lane, *_s for the special lane
+        T* ar_n = &r1[k]; T* ai_n = &i1[k]; T* br_n = &r2[R2 - 1 - k]; T* bi_n = &i2[R2 - 1 - k];
+        T* ar_s = (k < H) ? &r1[k] : &r2[k - H];
+        T* ai_s = (k < H) ? &i1[k] : &i2[k - H];
+        T* br_s = (k == 0) ? &r2[R2 - 1] : ((k < H) ? &r1[R2 - k] : &r2[R2 - 1 - (k - H)]);
+        T* bi_s = (k == 0) ? &i2[R2 - 1] : ((k < H) ? &i1[R2 - k] : &i2[R2 - 1 - (k - H)]);
         T y[4] = {T(0), T(0), T(0), T(0)};
-        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r1[R2 - k], i1[R2 - k], w, y[0], y[1], y[2], y[3]);
+        if constexpr (FWD)
+          slot_fwd<T>(sel(*ar_s, *ar_n), sel(*ai_s, *ai_n), sel(*br_s, *br_n), sel(*bi_s, *bi_n), w, y[0], y[1], y[2], y[3]);
         const int idx[4] = {kk, N - kk, M - kk, M + kk};
-        f((q * R2 + k) * 4, idx, y);
-        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], w, r1[k], i1[k], r1[R2 - k], i1[R2 - k]);
-      }
-#pragma unroll
-      for (int k = 0; k < R2 / 2; ++k) {
-        const int kk = C::S2 / 2 + C::S2 * k;
-        const SlotTw<T> w = slot_tw<T>(tb, kk);
-        T y[4] = {T(0), T(0), T(0), T(0)};
-        if constexpr (FWD) slot_fwd<T>(r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k], w, y[0], y[1], y[2], y[3]);
-        const int idx[4] = {kk, N - kk, M - kk, M + kk};
-        f((q * R2 + R2 / 2 + k) * 4, idx, y);
-        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], w, r2[k], i2[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
+        const bool live = (k > 0) || !sp;
+        f((q * R2 + k) * 4, idx, y, live, pc);
+        if (PIPE && k + 1 < R2) {  // requested before this slot's stores
+          const int kn = sp ? kk_of(k + 1) : fc_opaque(kap) + C::S2 * (k + 1);
+          wn = slot_tw<T>(tb, kn);
+          const int idn[4] = {kn, N - kn, M - kn, M + kn};
+          pn = pre((q * R2 + k + 1) * 4, idn);
+        }
+        st((q * R2 + k) * 4, idx, y, live);
+        if constexpr (ADJ) {
+          T nar, nai, nbr, nbi;
+          slot_adj<T>(y[0], y[1], y[2], y[3], w, nar, nai, nbr, nbi);
+          if (k == 0) {
+            *ar_n = sel(*ar_n, nar); *ai_n = sel(*ai_n, nai);
+            *br_n = sel(*br_n, nbr); *bi_n = sel(*bi_n, nbi);
+          } else {
+            if (k < H) {
+              *ar_n = nar; *ai_n = nai;
+            } else {
+              *ar_s = sel(nar, *ar_s); *ai_s = sel(nai, *ai_s);
+              *ar_n = sel(*ar_n, nar); *ai_n = sel(*ai_n, nai);
+            }
+            *br_s = sel(nbr, *br_s); *bi_s = sel(nbi, *bi_s);
+            *br_n = sel(*br_n, nbr); *bi_n = sel(*bi_n, nbi);
+          }
+        }
       }
     }
   }

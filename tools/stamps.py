@@ -28,6 +28,12 @@ for which, nblk in ((0, 1024), (1, 2048)):
         # program order of the k_col stamps: 0 entry, 1 staged, 2 fwd done, 5 spectral done, 3 reductions done, 4 inv done
         st = st[:, [0, 1, 2, 5, 3, 4] + list(range(6, NST))]
         names[1] = ['stage in (tile loads)', 'fwd passes', 'recombine+spectral (hat r/w)', 'block reduction', 'inv passes']
+    if which == 1:
+        w1 = st[:, 6:12]
+        w0 = st[:, :6]
+        okk = (w1[:, 0] > 0) & (w0[:, 0] > 0)
+        print('   wave 1 minus wave 0 arrival (median ticks):', [int(np.median((w1[okk, i] - w0[okk, i]))) for i in range(6)])
+        print('   wave 1 phases (median):', [int(np.median(w1[okk, i + 1] - w1[okk, i])) for i in range(5)])
     d = np.diff(st[:, :n + 1], axis=1)
     ok = np.all(d >= 0, axis=1) & (st[:, 0] > 0)
     d = d[ok]
