@@ -417,6 +417,19 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   const int kc = ct * C::CT + hh * C::C + sub;  // this group's column
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
+  T* hcol = hat + (size_t)kc * C::N;
+  // what the spectral stage reads per recombination slot (4 positions of this lane)
+  struct Fetched { T h[4]; double2 ls[4]; };
+  auto fetch = [&](int pbase, const int idx[4]) {
+    Fetched p;
+    const T* hl = hcol + fc_opaque(l);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      p.h[t] = hl[(size_t)(pbase + t) * C::G];
+      p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];  // {lambda_kr, sin^2(pi kr/N)}
+    }
+    return p;
+  };
   if constexpr (MODE != MODE_INV_NATURAL) {
     // ---- stage in: tile rows -> quads of this group's column.  The whole tile is requested
     // first (one HBM latency for both rounds), then it passes through LDS half by half.
@@ -472,7 +485,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   }
 
   // ---- recombination / spectral stage / adjoint recombination, in place per slot
-  T* hcol = hat + (size_t)kc * C::N;
   const double lam1 = st->lam1, lam2 = st->lam2;
   const double lc = lam[kc];
   const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc + 1] : 0.0;
@@ -481,18 +493,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   constexpr bool FWD = (MODE != MODE_INV_NATURAL);
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL);
   if constexpr (MODE == MODE_STEP) {
-    struct Fetched { T h[4]; double2 ls[4]; };
-    recombine<C, true, true, true>(re, im, tb, l,
-      [&](int pbase, const int idx[4]) {
-        Fetched p;
-        const T* hl = hcol + fc_opaque(l);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          p.h[t] = hl[(size_t)(pbase + t) * C::G];
-          p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];  // {lambda_kr, sin^2(pi kr/N)}
-        }
-        return p;
-      },
+    recombine<C, true, true, true>(re, im, tb, l, fetch,
       [&](int pbase, const int*, T y[4], bool live, const Fetched& p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {

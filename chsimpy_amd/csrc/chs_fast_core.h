@@ -611,6 +611,10 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
       SlotTw<T> wn;
       const int id0[4] = {kk0, N - kk0, M - kk0, M + kk0};
       decltype(pre(0, id0)) pn;
+      if constexpr (PIPE) {  // slot 0 of the loop below, requested ahead of the special lane's own slot
+        wn = slot_tw<T>(tb, kk0);
+        pn = pre(q * R2 * 4, id0);
+      }
       if (sp) {
         const SlotTw<T> w0 = slot_tw<T>(tb, 0), wh = slot_tw<T>(tb, M / 2);
         const int idx[4] = {0, M / 2, M, 3 * (M / 2)};
@@ -623,10 +627,6 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
           y[0] = a0; y[1] = b0; y[2] = a2; y[3] = b1;
         }
         f(q * R2 * 4, idx, y, true, p0);
-        if constexpr (PIPE) {
-          wn = slot_tw<T>(tb, kk0);
-          pn = pre(q * R2 * 4, id0);
-        }
         st(q * R2 * 4, idx, y, true);
         if constexpr (ADJ) {
           T gar, gai, gzr, gzi;
@@ -635,9 +635,6 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
           slot_adj<T>(y[1], y[3], T(0), T(0), wh, gar, gai, gzr, gzi);
           r1[H] = gar + gzr; i1[H] = gai + gzi;
         }
-      } else if constexpr (PIPE) {
-        wn = slot_tw<T>(tb, kk0);
-        pn = pre(q * R2 * 4, id0);
       }
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
