@@ -167,13 +167,12 @@ struct Engine {
   int nDiagBlocks = 0;
   int nColMinBlocks = 0;
 
-  // overlapped pipeline: k_step_tail(s) on `stream2` next to k_col(s+1) on `stream`
-  hipStream_t stream2 = nullptr;
-  hipEvent_t evRow[2] = {nullptr, nullptr};   // k_row_inv(s) done      (parity s & 1)
-  hipEvent_t evTail[2] = {nullptr, nullptr};  // k_step_tail(s) done    (parity s & 1)
-  bool tailPending[2] = {false, false};
+  // deferred tail: the bookkeeping of step s rides as one extra workgroup in k_col of step s+1;
+  // the partial sums ping-pong between two sets so that step s+1 does not overwrite what it reads
   double* partSet[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // Diag, Mu, E2, Ra
   int parity = 0;
+  bool tailDeferred = false;  // the tail of the previous step is still to run
+  int tailSet = 0;            // ... on this partial set
   hipEvent_t evA = nullptr, evB = nullptr;
   double lastStepMs = 0.0;
   StepTimer timer;
@@ -208,7 +207,9 @@ enum {
 // ---- pointwise / reduction launchers (chs_pointwise.hip) -------------------
 int chs_launch_mu(Engine* E);                 // dU -> dMU, partials
 int chs_launch_mu_colsums(Engine* E, int cs_offset);  // dU -> column-sum minimum of the adaptive-step integrand only
-int chs_launch_step_tail(Engine* E, int do_pre, hipStream_t stream);  // fused pipeline: record of step s + time-step control of step s+1
+struct TailArgs;
+TailArgs chs_tail_args(const Engine* E, int set, int do_pre);  // set < 0: the current partial-sum pointers
+int chs_launch_step_tail(Engine* E, int do_pre);  // fused pipeline: record of step s + time-step control of step s+1
 int chs_launch_pre(Engine* E);                // partials -> state (L2, delt, time)
 int chs_launch_spectral(Engine* E, const void* hmu);  // dHat <- (dHat + Seig*hmu)/CHeig (natural order)
 int chs_launch_sum(Engine* E, int ignore_halt);  // meanU <- mean(dU)

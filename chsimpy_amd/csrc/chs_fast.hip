@@ -22,6 +22,7 @@
 
 #include "chs_common.h"
 #include "chs_fast_core.h"
+#include "chs_tail.h"
 #include "chs_math.h"
 
 enum { MODE_STEP = 0, MODE_FWD_NATIVE = 1, MODE_FWD_NATURAL = 2, MODE_INV_NATURAL = 3 };
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
                                                 typename C::T* __restrict__ hat, typename C::T* __restrict__ nat,
                                                 FTables<typename C::T> tb, const double* __restrict__ lam,
                                                 const double* __restrict__ sinsq, DevState* __restrict__ st,
-                                                double* __restrict__ partE2) {
+                                                double* __restrict__ partE2, TailArgs ta) {
   using T = typename C::T;
   using CS = ColStage<C>;
   __shared__ double red[32];
@@ -404,6 +405,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   if constexpr (MODE == MODE_STEP) stagger_start<CHS_STAGGER_COL>();
   if constexpr (MODE == MODE_STEP) STAMP(1, 0);
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
+  if constexpr (MODE == MODE_STEP) {
+    // one workgroup beyond the tiles: the record of the PREVIOUS step and this step's time
+    // bookkeeping (chs_fast_step), next to the column pass instead of a launch of its own
+    if (blockIdx.x == C::N / C::C) {
+      step_tail_body<C::THREADS>(ta, st, reinterpret_cast<double*>(chs_dyn_lds));
+      return;
+    }
+  }
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
   // tile and the part of it this workgroup owns; the Q workgroups of a tile get block numbers
   // b, b+8, ...: same XCD under round-robin dispatch (speed only, see row_of_block)
@@ -660,18 +669,25 @@ struct Launch {
   static int col(Engine* E, int mode, const void* tin, void* tout, void* hat, void* nat) {
     const int grid = CC::N / CC::C;
     const FTables<T> tb = get_tables<T>(E);
+    TailArgs ta;
     switch (mode) {
-      case MODE_STEP:
-        k_col<CC, MODE_STEP><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+      case MODE_STEP: {
+        int g = grid;
+        if (E->tailDeferred) {
+          ta = chs_tail_args(E, E->tailSet, 1);
+          g = grid + 1;
+        }
+        k_col<CC, MODE_STEP><<<g, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
         break;
+      }
       case MODE_FWD_NATIVE:
-        k_col<CC, MODE_FWD_NATIVE><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_FWD_NATIVE><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
         break;
       case MODE_FWD_NATURAL:
-        k_col<CC, MODE_FWD_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_FWD_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
         break;
       default:
-        k_col<CC, MODE_INV_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2);
+        k_col<CC, MODE_INV_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
         break;
     }
     CHS_HIP(hipGetLastError());
@@ -820,17 +836,12 @@ int chs_fast_init(Engine* E) {
   E->nPartE2 = P->col_tiles;
   CHS_HIP(hipMalloc(&E->dPartE2, sizeof(double) * (size_t)E->nPartE2));
   CHS_HIP(hipMalloc(&E->dPartRa, sizeof(double) * 8));
-  // second set of partial sums + side stream for the overlapped tail (chs_fast_step)
+  // second set of partial sums for the deferred tail (chs_fast_step)
   E->partSet[0][0] = E->dPartDiag; E->partSet[0][1] = E->dPartMu; E->partSet[0][2] = E->dPartE2; E->partSet[0][3] = E->dPartRa;
   CHS_HIP(hipMalloc(&E->partSet[1][0], sizeof(double) * 4 * (size_t)(E->nDiagBlocks > E->N ? E->nDiagBlocks : E->N)));
   CHS_HIP(hipMalloc(&E->partSet[1][1], sizeof(double) * (size_t)(E->nBands > E->N ? E->nBands : E->N)));
   CHS_HIP(hipMalloc(&E->partSet[1][2], sizeof(double) * (size_t)E->nPartE2));
   CHS_HIP(hipMalloc(&E->partSet[1][3], sizeof(double) * 8));
-  CHS_HIP(hipStreamCreateWithFlags(&E->stream2, hipStreamNonBlocking));
-  for (int q = 0; q < 2; ++q) {
-    CHS_HIP(hipEventCreateWithFlags(&E->evRow[q], hipEventDisableTiming));
-    CHS_HIP(hipEventCreateWithFlags(&E->evTail[q], hipEventDisableTiming));
-  }
   return CHS_OK;
 }
 
@@ -848,13 +859,6 @@ void chs_fast_free(Engine* E) {
   if (E->dPartE2) hipFree(E->dPartE2);
   if (E->dPartRa) hipFree(E->dPartRa);
   E->dPartRa = nullptr;
-  for (int q = 0; q < 2; ++q) {
-    if (E->evRow[q]) hipEventDestroy(E->evRow[q]);
-    if (E->evTail[q]) hipEventDestroy(E->evTail[q]);
-    E->evRow[q] = E->evTail[q] = nullptr;
-  }
-  if (E->stream2) hipStreamDestroy(E->stream2);
-  E->stream2 = nullptr;
   E->dSinSq = nullptr; E->dPartE2 = nullptr;
   delete P;
   E->dTw = nullptr;
@@ -891,6 +895,7 @@ static void select_partial_set(Engine* E) {
 
 int chs_fast_prologue(Engine* E) {
   FastPlan* P = (FastPlan*)E->dTw;
+  E->tailDeferred = false;
   select_partial_set(E);  // sum(mu^2) must land where the first step's k_pre looks for it
   chs_slot_begin(E, SLOT_MU);
   const int rc = P->row_fwd(E, E->dU, E->dT1, true);
@@ -902,29 +907,22 @@ int chs_fast_prologue(Engine* E) {
 // EnergieEut(U_k) and partMu its sum of squares; on exit U_(k+1) is in HBM, the pointwise
 // diagnostics partials of U_(k+1) are ready for k_fin and, with fuse_next, T1/partMu are
 // ready for the next step.
-// Nothing k_step_tail decides can gate the next step when the time step is fixed, the energy rule
-// only records (full_sim) and there is no time limit: then the tail of step s may run on a second
-// stream next to k_col of step s+1 (NaN still halts everything, one step later at most).
-static bool can_overlap_tail(const Engine* E) {
+// Nothing the tail decides can gate the next step when the time step is fixed, the energy rule
+// only records (full_sim) and there is no time limit: then the tail of step s is deferred and rides
+// as one extra workgroup in k_col of step s+1 -- no launch of its own, nothing waits for it (NaN
+// still halts everything, one step later at most).  The partial sums alternate between two sets.
+static bool can_defer_tail(const Engine* E) {
   return !E->dc.adaptive_time && E->dc.full_sim && !(E->dc.time_limit_s > 0.0) && !E->timer.on &&
-         E->stream2 != nullptr;
+         E->partSet[0][0] != nullptr;
 }
 
 int chs_fast_step(Engine* E, bool first, bool last) {
   FastPlan* P = (FastPlan*)E->dTw;
   int rc;
-  const bool overlap = can_overlap_tail(E);
-  const int par = E->parity;
-  if (overlap) {
-    // partial sums ping-pong between two sets; the set is free once the tail that read it is done
-    if (E->tailPending[par]) {
-      CHS_HIP(hipStreamWaitEvent(E->stream, E->evTail[par], 0));
-      E->tailPending[par] = false;
-    }
-  }
+  const bool defer = can_defer_tail(E);
   select_partial_set(E);
   if (first) {
-    // time-step control of the first step of the call; later steps get it from k_step_tail.
+    // time-step control of the first step of the call; later steps get it from the tail.
     // The prologue wrote sum(mu^2) into the set that was current then: fold it in here.
     if (E->dc.adaptive_time) {
       if ((rc = chs_launch_mu_colsums(E, 0))) return rc;
@@ -932,8 +930,9 @@ int chs_fast_step(Engine* E, bool first, bool last) {
     if ((rc = chs_launch_pre(E))) return rc;
   }
   chs_slot_begin(E, SLOT_SPEC);
-  rc = P->col(E, MODE_STEP, E->dT1, E->dT2, E->dHat, nullptr);
+  rc = P->col(E, MODE_STEP, E->dT1, E->dT2, E->dHat, nullptr);  // + the previous step's deferred tail
   chs_slot_end(E, SLOT_SPEC);
+  E->tailDeferred = false;
   if (rc) return rc;
   chs_slot_begin(E, SLOT_INV);
   rc = P->row_inv(E, last ? ROW_INV_DIAG : ROW_INV_FUSED, E->dT2, E->dU, E->dT1);
@@ -944,21 +943,10 @@ int chs_fast_step(Engine* E, bool first, bool last) {
     // this step has not advanced computed_steps yet, hence the offset
     if ((rc = chs_launch_mu_colsums(E, 1))) return rc;
   }
-  if (!overlap) return chs_launch_step_tail(E, last ? 0 : 1, E->stream);
-  CHS_HIP(hipEventRecord(E->evRow[par], E->stream));
-  CHS_HIP(hipStreamWaitEvent(E->stream2, E->evRow[par], 0));
-  if ((rc = chs_launch_step_tail(E, last ? 0 : 1, E->stream2))) return rc;
-  CHS_HIP(hipEventRecord(E->evTail[par], E->stream2));
-  E->tailPending[par] = true;
+  if (last || !defer) return chs_launch_step_tail(E, last ? 0 : 1);
+  E->tailDeferred = true;
+  E->tailSet = E->parity;
   E->parity ^= 1;
-  if (last) {
-    // the call ends here: the main stream joins the side stream
-    for (int q = 0; q < 2; ++q)
-      if (E->tailPending[q]) {
-        CHS_HIP(hipStreamWaitEvent(E->stream, E->evTail[q], 0));
-        E->tailPending[q] = false;
-      }
-  }
   return CHS_OK;
 }
 

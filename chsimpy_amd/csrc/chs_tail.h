@@ -1,0 +1,146 @@
+// chs_tail.h -- the per-step bookkeeping of the fused pipeline: the record of step s (the thread-0
+// part of k_fin) and the time-step control of step s+1 (the thread-0 part of k_pre), written as a
+// workgroup-level device function so that it can run as its own one-block kernel (k_step_tail) or
+// as one extra workgroup of the next step's k_col (chs_fast.hip).
+#pragma once
+#include "chs_common.h"
+
+// thread-0 part of k_pre: solver.py:184-199,225 and utils.py:41-42
+__device__ __forceinline__ void pre_update(const DevConsts& dc, DevState* st, double musq, bool adapt, double delt_dyn) {
+#pragma clang fp contract(off)
+  const double N2 = (double)dc.N * (double)dc.N;
+  st->L2_cur = sqrt(musq) / N2;  // solver.py:225
+  double delt = st->delt;
+  if (adapt) {  // solver.py:184-188
+    const double delt_new = fmax(dc.delt0, delt_dyn);
+    if (delt_new / delt > 1.15)
+      delt = 0.75 * delt + 0.25 * delt_new;
+    else
+      delt = delt_new;
+    st->delt = delt;
+  }
+  const double lam1 = delt / dc.delx2;  // utils.py:41-42
+  st->lam1 = lam1;
+  st->lam2 = dc.kappa_tilde * lam1 / dc.delx2;
+  const double tds = st->time_delta_sum + delt;  // solver.py:195-199
+  st->time_delta_sum = tds;
+  const double tp = tds / dc.M_tilde;
+  st->time_passed = tp;
+  if (dc.time_limit_s > 0.0 && tp > dc.time_limit_s) {
+    st->stop_reason = CHS_STOP_TIME_LIMIT;
+    st->halt = 1;
+  }
+}
+
+// thread-0 part of the per-step record: solver.py:230-249 ; timedata.py:8-10,51-63
+__device__ __forceinline__ void fin_update(const DevConsts& dc, DevState* st, double E, double E2, double PS,
+                                           double SA, double Ra, double* __restrict__ rows, long long rowsCap) {
+  const long long k = st->rows_written;
+  if (k < rowsCap) {
+    double* row = rows + k * 9;
+    row[0] = (double)st->computed_steps; row[1] = E; row[2] = E2; row[3] = SA;
+    row[4] = st->time_passed; row[5] = Ra; row[6] = st->L2_cur; row[7] = PS; row[8] = st->delt;
+  }
+  st->rows_written = k + 1;
+  const double L2v = st->L2_cur, tp = st->time_passed;
+  if (E != E || E2 != E2 || Ra != Ra || PS != PS || L2v != L2v || tp != tp || SA != SA) {
+    st->nan_flag = 1;  // timedata.py:10 fires before computed_steps += 1
+    st->halt = 1;
+  } else {
+    const long long cs = st->computed_steps + 1;  // solver.py:240
+    st->computed_steps = cs;
+    // solver.py:242-249 ; timedata.py:63
+    if (!st->skip_check && st->E2_prev > E2 && E2 > st->E2_0) {
+      st->tau0 = (double)cs;
+      st->t0 = st->time_passed;
+      if (!dc.full_sim) {
+        st->stop_reason = CHS_STOP_ENERGY;
+        st->halt = 1;
+      } else {
+        st->skip_check = 1;
+      }
+    }
+    st->E2_prev = E2;
+  }
+}
+
+// Inputs of one tail.
+//   partDiag[nRow][4] = {sE, edge-row/column terms, sPS, cSA} and partRa from k_row_inv
+//   partE2[nE2]       = spectral gradient sums from k_col
+//   partMu[nMu]       = sum(mu^2) of the NEXT step's EnergieEut from k_row_inv (fused)
+struct TailArgs {
+  int enabled = 0, do_pre = 0;
+  DevConsts dc;
+  const double* partDiag = nullptr; const double* partE2 = nullptr; const double* partMu = nullptr;
+  const double* partColMin = nullptr; const double* partRa = nullptr;
+  int nRow = 0, nE2 = 0, nMu = 0, nColMin = 0;
+  double* rows = nullptr;
+  long long rowsCap = 0;
+};
+
+#define TAIL_NV 8
+#define TAIL_RED_DOUBLES(THREADS) (((THREADS) / 64 + 1) * (TAIL_NV + 1))
+
+// One workgroup of THREADS threads; `red` = TAIL_RED_DOUBLES(THREADS) doubles of LDS.  Every input
+// is requested up front, so the block pays one memory latency instead of a dozen.
+template <int THREADS>
+__device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __restrict__ st, double* red) {
+  constexpr int NW = THREADS / 64, NV = TAIL_NV;
+  double* tot = red + NW * (NV + 1);
+  const DevConsts& dc = ta.dc;
+  const int N = dc.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int do_pre = ta.do_pre;
+  const long long cs_next = st->computed_steps + 1;
+  const bool adapt = do_pre && dc.adaptive_time && cs_next > 500 && (cs_next % 2) == 0;
+  double v[NV] = {0, 0, 0, 0, 0, 0, 0, 0};  // sE, sEdge, sPS, cSA, spectral, musq, -, -
+  double mn = 1.0e300;
+  for (int i = tid; i < ta.nRow; i += THREADS) {
+    v[0] += ta.partDiag[(size_t)i * 4 + 0];
+    v[1] += ta.partDiag[(size_t)i * 4 + 1];
+    v[2] += ta.partDiag[(size_t)i * 4 + 2];
+    v[3] += ta.partDiag[(size_t)i * 4 + 3];
+  }
+  for (int i = tid; i < ta.nE2; i += THREADS) v[4] += ta.partE2[i];
+  if (do_pre)
+    for (int i = tid; i < ta.nMu; i += THREADS) v[5] += ta.partMu[i];
+  if (adapt)
+    for (int i = tid; i < ta.nColMin; i += THREADS) mn = fmin(mn, ta.partColMin[i]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  mn = wave_min(mn);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * (NV + 1) + i] = v[i];
+    red[wave * (NV + 1) + NV] = mn;
+  }
+  __syncthreads();
+  if (tid <= NV) {
+    double t = red[tid];
+    for (int w = 1; w < NW; ++w) t = (tid < NV) ? t + red[w * (NV + 1) + tid] : fmin(t, red[w * (NV + 1) + tid]);
+    tot[tid] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+#pragma clang fp contract(off)
+    const double Ra = ta.partRa[0];
+    const double N2 = (double)N * (double)N;
+    const double L2sq = dc.L * dc.L;
+    // np.gradient's sum of squares from the spectrum + the one-sided edge rows/columns (see k_fin)
+    const double sG = (4.0 * tot[4] + 3.0 * tot[1]) / (4.0 * dc.delx * dc.delx);
+    const double E2 = 0.5 * dc.Amr * dc.kappa_tilde * L2sq * (sG / N2);
+    const double E = dc.Amr * L2sq * (tot[0] / N2) + E2;
+    // work on a register copy of the state: one wide load and one wide store instead of a
+    // chain of dependent global round trips
+    DevState loc = *st;
+    fin_update(dc, &loc, E, E2, tot[2] / N2, tot[3] / N2, Ra, ta.rows, ta.rowsCap);
+    if (do_pre && !loc.halt) pre_update(dc, &loc, tot[5], adapt, tot[NV]);
+    // write back everything except meanU: when the tail rides in k_col of the NEXT step, that
+    // kernel may be storing it at this very moment (it is the only other writer of the state)
+    st->delt = loc.delt; st->time_delta_sum = loc.time_delta_sum; st->time_passed = loc.time_passed;
+    st->tau0 = loc.tau0; st->t0 = loc.t0; st->E2_0 = loc.E2_0; st->E2_prev = loc.E2_prev;
+    st->L2_cur = loc.L2_cur; st->lam1 = loc.lam1; st->lam2 = loc.lam2;
+    st->computed_steps = loc.computed_steps; st->rows_written = loc.rows_written;
+    st->skip_check = loc.skip_check; st->stop_reason = loc.stop_reason; st->nan_flag = loc.nan_flag;
+    st->halt = loc.halt;
+  }
+}
