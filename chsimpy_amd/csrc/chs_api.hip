@@ -328,6 +328,7 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   E->lastStepMs = ms;
   DevState s;
   CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+  if (s.halt) E->hat_valid = false;  // a deferred tail lets k_col run once past the stop (chs_fast_step)
   int64_t done = s.rows_written;
   if (done > nsteps) done = nsteps;
   if (steps_done) *steps_done = done;

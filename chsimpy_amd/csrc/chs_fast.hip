@@ -907,13 +907,14 @@ int chs_fast_prologue(Engine* E) {
 // EnergieEut(U_k) and partMu its sum of squares; on exit U_(k+1) is in HBM, the pointwise
 // diagnostics partials of U_(k+1) are ready for k_fin and, with fuse_next, T1/partMu are
 // ready for the next step.
-// Nothing the tail decides can gate the next step when the time step is fixed, the energy rule
-// only records (full_sim) and there is no time limit: then the tail of step s is deferred and rides
-// as one extra workgroup in k_col of step s+1 -- no launch of its own, nothing waits for it (NaN
-// still halts everything, one step later at most).  The partial sums alternate between two sets.
+// With a fixed time step and no time limit the tail of step s decides nothing the column pass of
+// step s+1 needs: it is deferred and rides as one extra workgroup in k_col of step s+1 -- no launch
+// of its own, nothing waits for it.  A stop it raises (energy rule, NaN) takes effect one kernel
+// later: k_col of step s+1 has then advanced hat_U and T2 once more, which nothing reads again
+// (k_row_inv sees `halt` and leaves U alone; hat_U is re-derived from U on the next call, as in
+// solver.py:159 -- run_steps drops hat_valid).  The partial sums alternate between two sets.
 static bool can_defer_tail(const Engine* E) {
-  return !E->dc.adaptive_time && E->dc.full_sim && !(E->dc.time_limit_s > 0.0) && !E->timer.on &&
-         E->partSet[0][0] != nullptr;
+  return !E->dc.adaptive_time && !(E->dc.time_limit_s > 0.0) && !E->timer.on && E->partSet[0][0] != nullptr;
 }
 
 int chs_fast_step(Engine* E, bool first, bool last) {

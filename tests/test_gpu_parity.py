@@ -162,6 +162,29 @@ def test_energy_stop_without_full_sim(gpu):
     assert sol.stop_reason == 'None' and sol.computed_steps == 100 and sol.tau0 == 72
 
 
+def test_resume_after_energy_stop(gpu):
+    """The device loop runs one column pass past an energy stop (deferred bookkeeping); the stop
+    step's U is what comes back and a further solve_or_resume continues from it exactly like the
+    reference (hat_U re-derived from U, solver.py:159; the stop rule fires again at once while
+    E2 keeps falling below its start value... or not at all -- whatever the oracle does)."""
+    kw = dict(full_sim=False, delt=3e-6)
+    p = make(64, 6000, 'auto', **kw)
+    s = chsimpy_amd.Solver(p)
+    o = orc.OracleSolver(orc.make_params(64, 6000, **kw))
+    s.prepare(); o.prepare()
+    sol = s.solve_or_resume(); o.solve_or_resume()
+    assert sol.stop_reason == 'energy' and sol.computed_steps == o.computed_steps == 72
+    assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0)
+    for chunk in (1, 5, 30):
+        sol = s.solve_or_resume(chunk); o.solve_or_resume(chunk)
+        assert sol.computed_steps == o.computed_steps
+        assert sol.stop_reason == o.stop_reason and sol.tau0 == o.tau0
+        assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0)
+    td, to = sol.timedata.data(), o.timedata.data()
+    assert td.shape == to.shape and np.allclose(td, to, rtol=1e-8, atol=1e-300)
+    s.close()
+
+
 def test_time_limit_stop(gpu):
     p = make(64, 500, 'auto', time_max=30 * 3e-8 / 1.71e-8 / 60)  # ~30 steps of simulated time
     sol, o = compare_run(p, dict(time_max=p.time_max))
