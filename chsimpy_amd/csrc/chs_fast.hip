@@ -94,6 +94,9 @@ __device__ __forceinline__ void stagger_start() {
 // ---- diagnostic build only (-DCHS_STAMPS): s_memtime stamps at the phase boundaries of the
 // row and column kernels, first wave of every workgroup; read back with chs_debug_stamps().
 // The stamp values go to a buffer nothing else reads; no output is computed from them.
+#ifndef CHS_ROW_PIPE
+#define CHS_ROW_PIPE false
+#endif
 #ifdef CHS_STAMPS
 #define CHS_NSTAMP 12
 __device__ unsigned long long g_stamps[2][8192 * CHS_NSTAMP];
@@ -332,13 +335,15 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     fwd_passes<C>(re, im, scr, tb, launder(l));
     if constexpr (DIAG && FUSE) STAMP(0, 5);
     __builtin_amdgcn_sched_barrier(0);
-    recombine<C, true, false, false>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
-                              [&](int, const int idx[4], T y[4], bool live, NoFetch) {
+    // (CHS_ROW_PIPE: twiddles of the next slot ahead of this slot's stores -- measured slower here)
+    recombine<C, true, false, CHS_ROW_PIPE>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
+                              [](int, const int*, T*, bool, NoFetch) {},
+                              [&](int, const int idx[4], T y[4], bool live) {
       if (live) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
       }
-    }, [](int, const int*, T*, bool) {});
+    });
   }
   if constexpr (DIAG && FUSE) STAMP(0, 6);
   if constexpr (DIAG) {
