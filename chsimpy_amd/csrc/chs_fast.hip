@@ -728,8 +728,15 @@ using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, 2, 1, 16, CH
 
 // fp32 configurations (BASELINE.json configs[3]: N = 8192 fp32): 32 complex values per lane
 // occupy the same 64 VGPRs as 16 fp64 ones; reductions and the spectral update stay in fp64.
-using G8192 = FCfg<float, 8192, 128, 512, 16, 4, 4, 16, 2, 1, 16, 4, 4>;
-using G8192C = FCfg<float, 8192, 128, 512, 16, 4, 4, 16, 2, 1, 16, 2, 4>;
+#ifndef CHS_G8192_WPS
+#define CHS_G8192_WPS 4
+#endif
+#ifndef CHS_G8192C_WPS
+#define CHS_G8192C_WPS 2
+#endif
+// N = 8192 fp32: four wavefronts per transform, 16 complex values per lane, four radix-8 passes
+using G8192 = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, 4>;
+using G8192C = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS, 4>;
 using G4096 = FCfg<float, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 4, 4>;
 using G4096C = FCfg<float, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 2, 4>;
 
