@@ -21,6 +21,39 @@
 #include <vector>
 
 #include "chs_common.h"
+#ifdef CHS_STAMPS
+#define CHS_NSTAMP 12
+__device__ unsigned long long g_stamps[2][8192 * CHS_NSTAMP];
+#define STAMP(K, I)                                                                         \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    unsigned long long t__;                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[K][blockIdx.x * CHS_NSTAMP + (I)] = t__; \
+  } while (0)
+// recombination-internal stamps of k_col<MODE_STEP> (the only PIPE user), slots 6..11
+#define CHS_RSTAMP(I) do { if constexpr (PIPE) STAMP(1, 6 + (I)); } while (0)
+// the same from wave 1 (the plain path), slots 10..11 + reuse: diagnostic builds only
+#define CHS_RSTAMP1(I)                                                                      \
+  do {                                                                                      \
+    if constexpr (PIPE) {                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                    \
+      unsigned long long t__;                                                               \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");          \
+      __builtin_amdgcn_sched_barrier(0);                                                    \
+      if (threadIdx.x == 64 && blockIdx.x < 8192) g_stamps[0][blockIdx.x * CHS_NSTAMP + 7 + (I)] = t__; \
+    }                                                                                       \
+  } while (0)
+extern "C" int chs_debug_stamps(int which, unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n,
+                                  sizeof(unsigned long long) * 8192 * CHS_NSTAMP * which);
+}
+#else
+#define STAMP(K, I) do {} while (0)
+#define CHS_RSTAMP(I) do {} while (0)
+#define CHS_RSTAMP1(I) do {} while (0)
+#endif
 #include "chs_fast_core.h"
 #include "chs_tail.h"
 #include "chs_math.h"
@@ -83,8 +116,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 template <int NSLEEP>
 __device__ __forceinline__ void stagger_start() {
   if constexpr (NSLEEP > 0) {
-    // blocks b and b + 256 are the two residents of one CU (8 XCDs x 32 CUs, dealt round-robin)
-    if ((blockIdx.x >> 8) & 1) {
+    // Delay every other workgroup of an XCD's dispatch order (j = blockIdx / 8), flipped every 32:
+    // whether the dispatcher fills a CU first (j, j+1) or deals across the 32 CUs first (j, j+32),
+    // the two residents of a CU start half a phase apart and keep that offset round after round.
+    const int j = blockIdx.x >> 3;
+    if ((j ^ (j >> 5)) & 1) {
 #pragma unroll 1
       for (int i = 0; i < NSLEEP; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -94,27 +130,21 @@ __device__ __forceinline__ void stagger_start() {
 // ---- diagnostic build only (-DCHS_STAMPS): s_memtime stamps at the phase boundaries of the
 // row and column kernels, first wave of every workgroup; read back with chs_debug_stamps().
 // The stamp values go to a buffer nothing else reads; no output is computed from them.
+// ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
+#ifndef CHS_COL_PARK
+#define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
+#endif
+#ifndef CHS_COL_PRELOAD
+#define CHS_COL_PRELOAD 2  // 2: request the whole tile before staging it; 1: half by half (fewer registers)
+#endif
+#ifndef CHS_COL_LDS_PAD
+#define CHS_COL_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower k_col's occupancy
+#endif
+#ifndef CHS_COL_PIPE
+#define CHS_COL_PIPE 1     // recombine<PIPE>: 1 = next slot's loads ahead of this slot's stores, 2 = a slot earlier
+#endif
 #ifndef CHS_ROW_PIPE
 #define CHS_ROW_PIPE false
-#endif
-#ifdef CHS_STAMPS
-#define CHS_NSTAMP 12
-__device__ unsigned long long g_stamps[2][8192 * CHS_NSTAMP];
-#define STAMP(K, I)                                                                         \
-  do {                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-    unsigned long long t__;                                                                 \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[K][blockIdx.x * CHS_NSTAMP + (I)] = t__; \
-    if ((K) == 1 && threadIdx.x == 64 && blockIdx.x < 8192) g_stamps[K][blockIdx.x * CHS_NSTAMP + (I) + 6] = t__; \
-  } while (0)
-extern "C" int chs_debug_stamps(int which, unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n,
-                                  sizeof(unsigned long long) * 8192 * CHS_NSTAMP * which);
-}
-#else
-#define STAMP(K, I) do {} while (0)
 #endif
 
 // Returns x through an opaque asm so that index arithmetic derived from it is not CSE'd
@@ -432,26 +462,36 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
   T* hcol = hat + (size_t)kc * C::N;
-  // what the spectral stage reads per recombination slot (4 positions of this lane)
-  struct Fetched { T h[4]; double2 ls[4]; };
+  // What the spectral stage reads per recombination slot (4 positions of this lane): {lambda_kr,
+  // sin^2(pi kr/N)} from the table (L2), fetched one slot ahead, and hat_U.  The lane's 2E values of
+  // hat_U are parked in LDS long before they are needed (every lane reads back only what it wrote,
+  // so no barrier guards the parking slots themselves):
+  //   positions 0..E-1   requested with the tile at kernel entry -> hpark1 (its own LDS area)
+  //   positions E..2E-1  requested after the forward passes      -> hpark2 = the exchange scratch,
+  //                      idle until the inverse passes
+  struct Fetched { double2 ls[4]; T h[(CHS_COL_PARK != 0) ? 1 : 4]; };
   auto fetch = [&](int pbase, const int idx[4]) {
     Fetched p;
-    const T* hl = hcol + fc_opaque(l);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      p.h[t] = hl[(size_t)(pbase + t) * C::G];
-      p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];  // {lambda_kr, sin^2(pi kr/N)}
+    for (int t = 0; t < 4; ++t) p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];
+    if constexpr (CHS_COL_PARK == 0) {
+      const T* hl = hcol + fc_opaque(l);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) p.h[t] = hl[(size_t)(pbase + t) * C::G];
     }
     return p;
   };
+  constexpr bool PARK = (MODE == MODE_STEP) && (CHS_COL_PARK != 0);
+  T* hpark1 = lds + col_lds_elems<C>() + threadIdx.x;
+  T* hpark2 = lds + threadIdx.x;
+  T hearly[PARK ? C::E : 1];
   if constexpr (MODE != MODE_INV_NATURAL) {
     // ---- stage in: tile rows -> quads of this group's column.  The whole tile is requested
     // first (one HBM latency for both rounds), then it passes through LDS half by half.
     const T* tile = Tin + (size_t)ct * C::N * C::CT;
     constexpr int PER = CS::PER;
     T stage[2][2 * PER];
-#pragma unroll
-    for (int rho = 0; rho < 2; ++rho) {
+    auto request = [&](int rho) {
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int f = 2 * (threadIdx.x + i * C::THREADS);
@@ -464,10 +504,19 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
           stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
         }
       }
+    };
+    request(0);
+    if constexpr (CHS_COL_PRELOAD == 2) request(1);
+    if constexpr (PARK) {
+#pragma unroll
+      for (int p = 0; p < C::E; ++p) hearly[p] = hcol[(size_t)p * C::G + l];
     }
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
       __syncthreads();
+      if constexpr (CHS_COL_PRELOAD != 2) {
+        if (rho == 1) request(1);
+      }
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int f = 2 * (threadIdx.x + i * C::THREADS);
@@ -494,8 +543,20 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     }
     __syncthreads();
     if constexpr (MODE == MODE_STEP) STAMP(1, 1);
+    if constexpr (PARK) {
+#pragma unroll
+      for (int p = 0; p < C::E; ++p) hpark1[p * C::THREADS] = hearly[p];
+    }
     fwd_passes<C>(re, im, scr, tb, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 2);
+    if constexpr (PARK) {
+      __syncthreads();  // every wavefront has read its last exchange: the scratch is free
+      T hlate[C::E];
+#pragma unroll
+      for (int p = 0; p < C::E; ++p) hlate[p] = hcol[(size_t)(C::E + p) * C::G + l];
+#pragma unroll
+      for (int p = 0; p < C::E; ++p) hpark2[p * C::THREADS] = hlate[p];
+    }
   }
 
   // ---- recombination / spectral stage / adjoint recombination, in place per slot
@@ -507,11 +568,18 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   constexpr bool FWD = (MODE != MODE_INV_NATURAL);
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL);
   if constexpr (MODE == MODE_STEP) {
-    recombine<C, true, true, true>(re, im, tb, l, fetch,
+    recombine<C, true, true, CHS_COL_PIPE>(re, im, tb, l, fetch,
       [&](int pbase, const int*, T y[4], bool live, const Fetched& p) {
+        T hold[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const T h = chs_spectral<T>(p.h[t], y[t], p.ls[t].x, lc, lam1, lam2);
+          const int pos = pbase + t;  // compile-time after unrolling
+          if constexpr (PARK) hold[t] = (pos < C::E) ? hpark1[pos * C::THREADS] : hpark2[(pos - C::E) * C::THREADS];
+          else hold[t] = p.h[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const T h = chs_spectral<T>(hold[t], y[t], p.ls[t].x, lc, lam1, lam2);
           y[t] = h;
           const double term = (double)h * (double)h * (p.ls[t].y + sqc);
           e2 += live ? term : 0.0;
@@ -549,6 +617,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   }
   if constexpr (MODE == MODE_STEP) STAMP(1, 3);
   if constexpr (ADJ) {
+    // wave-local groups exchange behind wavefront fences only: the parked hat_U of another
+    // wavefront may lie in this group's scratch, so everybody must be through the spectral stage
+    if constexpr (PARK && C::WAVE_LOCAL) __syncthreads();
     inv_passes<C>(re, im, scr, tb, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 4);
     // ---- stage out: quads -> tile rows
@@ -623,7 +694,8 @@ template <class C, class CC = C>
 struct Launch {
   using T = typename C::T;
   static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T);
-  static constexpr size_t col_lds = (size_t)col_lds_elems<CC>() * sizeof(T);
+  // + the parking area of half a hat_U column per lane (k_col<MODE_STEP>)
+  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (CHS_COL_PARK ? (size_t)CC::E * CC::THREADS : 0)) * sizeof(T) + CHS_COL_LDS_PAD;
   static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
 
   template <class K>

@@ -536,6 +536,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<I0 + 1, I1>(f);
   }
 }
+#ifndef CHS_RSTAMP
+#define CHS_RSTAMP(I) do {} while (0)
+#define CHS_RSTAMP1(I) do {} while (0)
+#endif
 struct NoFetch {};
 // x through an opaque asm: address arithmetic derived from it is redone at the point of use instead
 // of being computed for all slots up front and kept in registers
@@ -544,13 +548,14 @@ __device__ __forceinline__ int fc_opaque(int x) {
   return x;
 }
 
-// Recombination slots of one lane.  PIPE: the twiddles of slot k+1 and whatever `pre(pbase, idx)`
+// Recombination slots of one lane.  PIPE = 1: the twiddles of slot k+1 and whatever `pre(pbase, idx)`
 // fetches for it (global loads only) are requested after slot k's `f(pbase, idx, y, live, fetched)`
-// has computed its results and before `st(pbase, idx, y, live)` stores them.  A load requested after
+// has computed its results and before `st(pbase, idx, y, live)` stores them; PIPE = 2: already at the
+// start of slot k (a whole slot of latency cover for more live registers).  A load requested after
 // a store cannot be waited for without waiting for the store too (one in-order vmcnt counter), so
 // without this every slot would sit out the full latency of the previous slot's stores.
-// !PIPE: everything of slot k is fetched in slot k (f may load and store as it likes, st is empty).
-template <class C, bool FWD, bool ADJ, bool PIPE, class PRE, class F, class ST>
+// PIPE = 0: everything of slot k is fetched in slot k (f may load and store as it likes, st is empty).
+template <class C, bool FWD, bool ADJ, int PIPE, class PRE, class F, class ST>
 __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, const FTables<typename C::T>& tb,
                                           int l, PRE&& pre, F&& f, ST&& st) {
   using T = typename C::T;
@@ -574,8 +579,11 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
         wn = slot_tw<T>(tb, kap);
         pn = pre(q * R2 * 4, id0);
       }
+      CHS_RSTAMP1(0);
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
+        if (k == 1) CHS_RSTAMP1(1);
+        if (k == 4) CHS_RSTAMP1(2);
         const int kk = kap + C::S2 * k;
         if (!PIPE) {
           wn = slot_tw<T>(tb, kk);
@@ -584,19 +592,22 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
         }
         const SlotTw<T> w = wn;  // shared by the forward and the adjoint half
         const auto pc = pn;
-        T y[4] = {T(0), T(0), T(0), T(0)};
-        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k], w, y[0], y[1], y[2], y[3]);
-        const int idx[4] = {kk, N - kk, M - kk, M + kk};
-        f((q * R2 + k) * 4, idx, y, true, pc);
-        if (PIPE && k + 1 < R2) {  // requested before this slot's stores
+        auto fetch_next = [&]() {
           const int kn = fc_opaque(kap) + C::S2 * (k + 1);
           wn = slot_tw<T>(tb, kn);
           const int idn[4] = {kn, N - kn, M - kn, M + kn};
           pn = pre((q * R2 + k + 1) * 4, idn);
-        }
+        };
+        if (PIPE == 2 && k + 1 < R2) fetch_next();  // a whole slot ahead of its use
+        T y[4] = {T(0), T(0), T(0), T(0)};
+        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k], w, y[0], y[1], y[2], y[3]);
+        const int idx[4] = {kk, N - kk, M - kk, M + kk};
+        f((q * R2 + k) * 4, idx, y, true, pc);
+        if (PIPE == 1 && k + 1 < R2) fetch_next();  // requested before this slot's stores
         st((q * R2 + k) * 4, idx, y, true);
         if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], w, r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
       }
+      CHS_RSTAMP1(3);
     } else {
       const bool sp = (kap == 0);
       // The special lane: butterfly 0 pairs k <-> R2-k, butterfly S2/2 pairs k <-> R2-1-k.  Its slot
@@ -615,6 +626,7 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
         wn = slot_tw<T>(tb, kk0);
         pn = pre(q * R2 * 4, id0);
       }
+      CHS_RSTAMP(0);
       if (sp) {
         const SlotTw<T> w0 = slot_tw<T>(tb, 0), wh = slot_tw<T>(tb, M / 2);
         const int idx[4] = {0, M / 2, M, 3 * (M / 2)};
@@ -636,8 +648,11 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
           r1[H] = gar + gzr; i1[H] = gai + gzi;
         }
       }
+      CHS_RSTAMP(1);
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
+        if (k == 1) CHS_RSTAMP(2);
+        if (k == 4) CHS_RSTAMP(3);
         const int kk = kk_of(k);
         if (!PIPE) {
           wn = slot_tw<T>(tb, kk);
@@ -646,6 +661,14 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
         }
         const SlotTw<T> w = wn;
         const auto pc = pn;
+        auto fetch_next = [&]() {
+          const int kap_o = fc_opaque(kap);  // (unconditional: an asm in one arm of a select becomes a branch)
+          const int kn = sp ? kk_of(k + 1) : kap_o + C::S2 * (k + 1);
+          wn = slot_tw<T>(tb, kn);
+          const int idn[4] = {kn, N - kn, M - kn, M + kn};
+          pn = pre((q * R2 + k + 1) * 4, idn);
+        };
+        if (PIPE == 2 && k + 1 < R2) fetch_next();
         // operand registers: *_n for every other lane, *_s for the special lane
         T* ar_n = &r1[k]; T* ai_n = &i1[k]; T* br_n = &r2[R2 - 1 - k]; T* bi_n = &i2[R2 - 1 - k];
         T* ar_s = (k < H) ? &r1[k] : &r2[k - H];
@@ -658,12 +681,7 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
         const int idx[4] = {kk, N - kk, M - kk, M + kk};
         const bool live = (k > 0) || !sp;
         f((q * R2 + k) * 4, idx, y, live, pc);
-        if (PIPE && k + 1 < R2) {  // requested before this slot's stores
-          const int kn = sp ? kk_of(k + 1) : fc_opaque(kap) + C::S2 * (k + 1);
-          wn = slot_tw<T>(tb, kn);
-          const int idn[4] = {kn, N - kn, M - kn, M + kn};
-          pn = pre((q * R2 + k + 1) * 4, idn);
-        }
+        if (PIPE == 1 && k + 1 < R2) fetch_next();  // requested before this slot's stores
         st((q * R2 + k) * 4, idx, y, live);
         if constexpr (ADJ) {
           T nar, nai, nbr, nbi;

@@ -19,7 +19,7 @@ lib = _lib.load()
 lib.chs_debug_stamps.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
 names = {0: ['recombine^T (T2 loads)', 'inv passes', 'store U', 'pointwise (+edges)', 'fwd passes', 'recombine (T1 stores)'],
          1: ['stage in (tile loads)', 'fwd passes', 'spectral (hat r/w)', 'inv passes', 'stage out']}
-for which, nblk in ((0, 1024), (1, 2048)):
+for which, nblk in ((0, 2048), (1, 2048)):
     buf = np.zeros(8192 * NST, dtype=np.uint64)
     rc = lib.chs_debug_stamps(which, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size)
     st = buf.reshape(8192, NST)[:nblk].astype(np.int64)
@@ -28,12 +28,17 @@ for which, nblk in ((0, 1024), (1, 2048)):
         # program order of the k_col stamps: 0 entry, 1 staged, 2 fwd done, 5 spectral done, 3 reductions done, 4 inv done
         st = st[:, [0, 1, 2, 5, 3, 4] + list(range(6, NST))]
         names[1] = ['stage in (tile loads)', 'fwd passes', 'recombine+spectral (hat r/w)', 'block reduction', 'inv passes']
+    if which == 0:
+        r1 = st[:, 7:11]   # wave 1 of k_col (plain recombination path) parks its stamps in kernel 0's free slots
+        k1 = r1[:, 0] > 0
+        print('   k_col wave 1 (plain path): slot 0', int(np.median(r1[k1, 1] - r1[k1, 0])), '| slots 1-3',
+              int(np.median(r1[k1, 2] - r1[k1, 1])), '| slots 4-7', int(np.median(r1[k1, 3] - r1[k1, 2])))
     if which == 1:
-        w1 = st[:, 6:12]
-        w0 = st[:, :6]
-        okk = (w1[:, 0] > 0) & (w0[:, 0] > 0)
-        print('   wave 1 minus wave 0 arrival (median ticks):', [int(np.median((w1[okk, i] - w0[okk, i]))) for i in range(6)])
-        print('   wave 1 phases (median):', [int(np.median(w1[okk, i + 1] - w1[okk, i])) for i in range(5)])
+        r = st[:, 6:10]
+        okk = (r[:, 0] > 0) & (st[:, 2] > 0)
+        print('   wave 0 inside the recombination: fwd done -> enter', int(np.median(r[okk, 0] - st[okk, 2])),
+              '| special slot', int(np.median(r[okk, 1] - r[okk, 0])), '| slot 0', int(np.median(r[okk, 2] - r[okk, 1])),
+              '| slots 1-3', int(np.median(r[okk, 3] - r[okk, 2])), '| slots 4-7', int(np.median(st[okk, 5] - r[okk, 3])))
     d = np.diff(st[:, :n + 1], axis=1)
     ok = np.all(d >= 0, axis=1) & (st[:, 0] > 0)
     d = d[ok]
