@@ -130,6 +130,9 @@ __device__ __forceinline__ void stagger_start() {
 // ---- diagnostic build only (-DCHS_STAMPS): s_memtime stamps at the phase boundaries of the
 // row and column kernels, first wave of every workgroup; read back with chs_debug_stamps().
 // The stamp values go to a buffer nothing else reads; no output is computed from them.
+#ifndef CHS_ALWAYS_STORE_U
+#define CHS_ALWAYS_STORE_U 0  // 1: write U to HBM on every step even when nothing can read it
+#endif
 // ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
 #ifndef CHS_COL_PARK
 #define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
                                                     typename C::T* __restrict__ T1, FTables<typename C::T> tb,
                                                     DevConsts dc, const DevState* __restrict__ st,
                                                     double* __restrict__ partDiag, double* __restrict__ partMu,
-                                                    double* __restrict__ partRa) {
+                                                    double* __restrict__ partRa, int store_u) {
   using T = typename C::T;
   __shared__ double red[64];
   if (st->halt) return;
@@ -254,6 +257,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   double sEdge = 0.0;
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int ls = launder(l);
+  // FUSE: between the steps of one call nothing reads U from HBM (the next step continues from the
+  // registers) except the np.gradient edge terms below, which look at rows 1 and N-2: with
+  // store_u == 0 only the first and the last workgroup write their rows (chs_fast_step decides).
+  const bool write_u = !FUSE || store_u || row0 == 0 || row0 == C::N - C::C;
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
     const int m1 = ls + C::G * q, m2 = C::L1 - 1 - m1;
@@ -261,8 +268,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     for (int j = 0; j < C::R0 / 2; ++j) {
       T q1[4], q2[4];
       unpack_quads<C>(re, im, q, j, q1, q2);
-      store4<T>(urow + 4 * (size_t)(m1 + C::L1 * j), q1);
-      store4<T>(urow + 4 * (size_t)(m2 + C::L1 * j), q2);
+      if (write_u) {
+        store4<T>(urow + 4 * (size_t)(m1 + C::L1 * j), q1);
+        store4<T>(urow + 4 * (size_t)(m2 + C::L1 * j), q2);
+      }
       if constexpr (DIAG) {
         // np.gradient edge columns: (U[r,1]-U[r,0]) and (U[r,N-1]-U[r,N-2]) live in lane 0
         if (q == 0 && j == 0 && m1 == 0) {
@@ -733,13 +742,13 @@ struct Launch {
     const FTables<T> tb = get_tables<T>(E);
     if (mode == ROW_INV_PLAIN)
       k_row_inv<C, false, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                    E->dPartDiag, E->dPartMu, E->dPartRa);
+                                                                    E->dPartDiag, E->dPartMu, E->dPartRa, 1);
     else if (mode == ROW_INV_DIAG)
       k_row_inv<C, true, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                   E->dPartDiag, E->dPartMu, E->dPartRa);
+                                                                   E->dPartDiag, E->dPartMu, E->dPartRa, 1);
     else
       k_row_inv<C, true, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                  E->dPartDiag, E->dPartMu, E->dPartRa);
+                                                                  E->dPartDiag, E->dPartMu, E->dPartRa, E->storeU ? 1 : 0);
     CHS_HIP(hipGetLastError());
     return CHS_OK;
   }
@@ -1005,6 +1014,9 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   FastPlan* P = (FastPlan*)E->dTw;
   int rc;
   const bool defer = can_defer_tail(E);
+  // U between the steps of a call: nobody reads it unless a stop can end the call early (then the
+  // U of the stopping step is what the caller gets, solver.py:242-251) or the adaptive step sweeps it
+  E->storeU = E->dc.adaptive_time || (E->dc.time_limit_s > 0.0) || !E->dc.full_sim || CHS_ALWAYS_STORE_U;
   select_partial_set(E);
   if (first) {
     // time-step control of the first step of the call; later steps get it from the tail.

@@ -118,7 +118,12 @@ int chs_prepare(chs_handle h, double row0[9]);
  * `*steps_done` how many were completed (fewer than nsteps after an energy or
  * time-limit stop, which are decided on the device, solver.py:197-199,242-249).
  * Returns CHS_ENAN when a recorded scalar is NaN (timedata.py:10); the rows up
- * to and including the NaN row are still returned. */
+ * to and including the NaN row are still returned, the field is unspecified then
+ * (the reference raises before it assigns solution.U, solver.py:251).
+ * The device keeps the field of intermediate steps in registers where nothing can
+ * observe it (full_sim, fixed time step, no time limit: no stop can end the call
+ * early); chs_get_U after the call returns the field of the last completed step in
+ * every mode, exactly as `self.solution.U = U` after the reference's loop. */
 int chs_step_n(chs_handle h, int64_t nsteps, int32_t flags, double* rows, int64_t* steps_done);
 /* flags for chs_step_n */
 #define CHS_STEP_CARRY_HAT 1 /* do not re-derive hat_U on entry: continue the loop of the
