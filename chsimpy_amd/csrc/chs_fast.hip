@@ -133,6 +133,9 @@ __device__ __forceinline__ void stagger_start() {
 #ifndef CHS_ALWAYS_STORE_U
 #define CHS_ALWAYS_STORE_U 0  // 1: write U to HBM on every step even when nothing can read it
 #endif
+#ifndef CHS_ALIAS_T
+#define CHS_ALIAS_T 1
+#endif
 // ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
 #ifndef CHS_COL_PARK
 #define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
@@ -1027,12 +1030,16 @@ int chs_fast_step(Engine* E, bool first, bool last) {
     if ((rc = chs_launch_pre(E))) return rc;
   }
   chs_slot_begin(E, SLOT_SPEC);
-  rc = P->col(E, MODE_STEP, E->dT1, E->dT2, E->dHat, nullptr);  // + the previous step's deferred tail
+  // T2 (columns inverted) overwrites T1 in place: every workgroup of k_col reads exactly the part
+  // of the tile it later writes, every workgroup of the fused row kernel likewise for its rows --
+  // one array less in the per-step working set (T + hat_U = 268 MB next to a 256 MB Infinity Cache)
+  void* T2 = CHS_ALIAS_T ? E->dT1 : E->dT2;
+  rc = P->col(E, MODE_STEP, E->dT1, T2, E->dHat, nullptr);  // + the previous step's deferred tail
   chs_slot_end(E, SLOT_SPEC);
   E->tailDeferred = false;
   if (rc) return rc;
   chs_slot_begin(E, SLOT_INV);
-  rc = P->row_inv(E, last ? ROW_INV_DIAG : ROW_INV_FUSED, E->dT2, E->dU, E->dT1);
+  rc = P->row_inv(E, last ? ROW_INV_DIAG : ROW_INV_FUSED, T2, E->dU, E->dT1);
   chs_slot_end(E, SLOT_INV);
   if (rc) return rc;
   if (!last && E->dc.adaptive_time) {
