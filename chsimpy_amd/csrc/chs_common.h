@@ -172,6 +172,7 @@ struct Engine {
   double* partSet[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // Diag, Mu, E2, Ra
   int parity = 0;
   bool tailDeferred = false;  // the tail of the previous step is still to run
+  unsigned stepCount = 0;     // k_col<MODE_STEP> launches so far (tile walk direction alternates)
   bool storeU = true;         // the fused row kernel writes U on intermediate steps (chs_fast_step)
   int tailSet = 0;            // ... on this partial set
   hipEvent_t evA = nullptr, evB = nullptr;

@@ -136,6 +136,9 @@ __device__ __forceinline__ void stagger_start() {
 #ifndef CHS_ALIAS_T
 #define CHS_ALIAS_T 1
 #endif
+#ifndef CHS_COL_ZIGZAG
+#define CHS_COL_ZIGZAG 1
+#endif
 // ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
 #ifndef CHS_COL_PARK
 #define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
@@ -470,6 +473,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     ct = xcd + 8 * (j / CS::Q); hh = j % CS::Q;
   }
+  if constexpr (MODE == MODE_STEP) {
+    // every other step walks the tiles in the opposite direction: what the previous step touched
+    // last (hat_U of its last tiles, still in the 256 MB Infinity Cache) is touched first
+    if (ta.reverse) ct = C::N / C::CT - 1 - ct;
+  }
   const int kc = ct * C::CT + hh * C::C + sub;  // this group's column
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
@@ -766,6 +774,8 @@ struct Launch {
           ta = chs_tail_args(E, E->tailSet, 1);
           g = grid + 1;
         }
+        ta.reverse = (CHS_COL_ZIGZAG && (E->stepCount & 1)) ? 1 : 0;
+        ++E->stepCount;
         k_col<CC, MODE_STEP><<<g, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
         break;
       }

@@ -70,6 +70,7 @@ __device__ __forceinline__ void fin_update(const DevConsts& dc, DevState* st, do
 //   partMu[nMu]       = sum(mu^2) of the NEXT step's EnergieEut from k_row_inv (fused)
 struct TailArgs {
   int enabled = 0, do_pre = 0;
+  int reverse = 0;  // (k_col rider, not a tail input) walk the column tiles in descending order this step
   DevConsts dc;
   const double* partDiag = nullptr; const double* partE2 = nullptr; const double* partMu = nullptr;
   const double* partColMin = nullptr; const double* partRa = nullptr;
