@@ -107,6 +107,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 // Start-up stagger (experiment knob): every second workgroup of an XCD sleeps for
 // CHS_STAGGER x ~3.5 us before its first load, so that the memory phase of one half overlaps the
 // compute phase of the other (a kernel here has only 2-4 rounds of workgroups: no steady state).
+#ifndef CHS_STAGGER_UNIT
+#define CHS_STAGGER_UNIT 127
+#endif
 #ifndef CHS_STAGGER_ROW
 #define CHS_STAGGER_ROW 0
 #endif
@@ -122,7 +125,7 @@ __device__ __forceinline__ void stagger_start() {
     const int j = blockIdx.x >> 3;
     if ((j ^ (j >> 5)) & 1) {
 #pragma unroll 1
-      for (int i = 0; i < NSLEEP; ++i) __builtin_amdgcn_s_sleep(127);
+      for (int i = 0; i < NSLEEP; ++i) __builtin_amdgcn_s_sleep(CHS_STAGGER_UNIT);  // 64 cycles per unit
     }
   }
 }
