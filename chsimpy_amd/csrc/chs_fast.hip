@@ -248,6 +248,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
   if constexpr (DIAG && FUSE) stagger_start<CHS_STAGGER_ROW>();
+  const double mean_u = st->meanU;  // requested at entry (k_col of this step wrote it), used in the pointwise part
   const int row0 = row_of_block<C>(blockIdx.x);
   const int row = row0 + sub;
   T* scr = lds + (size_t)sub * C::SCR;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       __syncthreads();
     }
     const T RT = (T)dc.RT, BRT = (T)dc.BRT, B = (T)dc.B, A0 = (T)dc.A0, A1 = (T)dc.A1;
-    const double mean = st->meanU, thr = dc.threshold;
+    const double mean = mean_u, thr = dc.threshold;
     double sE = 0.0, sPS = 0.0, cSA = 0.0, s2 = 0.0;
     // One domain check per grid point (numpy: log of a non-positive number is NaN / -inf, which
     // the reference turns into its NaN assertion, timedata.py:10): the sums are poisoned at the end.
@@ -485,6 +486,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
   T* hcol = hat + (size_t)kc * C::N;
+  // constants of the spectral stage, requested here: their latency disappears behind the stage-in
+  // (loaded where they are used they cost every workgroup ~4 K cycles of waiting)
+  const double lam1 = st->lam1, lam2 = st->lam2;
+  const double lc = lam[kc];
+  const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc + 1] : 0.0;
   // What the spectral stage reads per recombination slot (4 positions of this lane): {lambda_kr,
   // sin^2(pi kr/N)} from the table (L2), fetched one slot ahead, and hat_U.  The lane's 2E values of
   // hat_U are parked in LDS long before they are needed (every lane reads back only what it wrote,
@@ -583,9 +589,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   }
 
   // ---- recombination / spectral stage / adjoint recombination, in place per slot
-  const double lam1 = st->lam1, lam2 = st->lam2;
-  const double lc = lam[kc];
-  const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc + 1] : 0.0;
   double e2 = 0.0;
   T h00 = T(0);
   constexpr bool FWD = (MODE != MODE_INV_NATURAL);
