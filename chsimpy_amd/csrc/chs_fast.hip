@@ -811,7 +811,7 @@ using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 #define CHS_ROW_WPS 4
 #endif
 #ifndef CHS_ROW_THREADS
-#define CHS_ROW_THREADS 512
+#define CHS_ROW_THREADS 256
 #endif
 // row kernels: CHS_ROW_THREADS/128 rows per workgroup, tiles of 4 columns
 using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS_ROW_WPS, 4>;
