@@ -268,65 +268,42 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int ls = launder(l);
   // FUSE: between the steps of one call nothing reads U from HBM (the next step continues from the
-  // registers) except the np.gradient edge terms below, which look at rows 1 and N-2: with
-  // store_u == 0 only the first and the last workgroup write their rows (chs_fast_step decides).
-  const bool write_u = !FUSE || store_u || row0 == 0 || row0 == C::N - C::C;
+  // registers) except the tail's np.gradient row-edge terms, which look at rows 0, 1, N-2, N-1: with
+  // store_u == 0 only the workgroups owning those rows write them (chs_fast_step decides).
+  const bool write_u = !FUSE || store_u || row0 < 2 || row0 + C::C > C::N - 2;
+  if (write_u) {
 #pragma unroll
-  for (int q = 0; q < C::NP0; ++q) {
-    const int m1 = ls + C::G * q, m2 = C::L1 - 1 - m1;
+    for (int q = 0; q < C::NP0; ++q) {
+      const int m1 = ls + C::G * q, m2 = C::L1 - 1 - m1;
 #pragma unroll
-    for (int j = 0; j < C::R0 / 2; ++j) {
-      T q1[4], q2[4];
-      unpack_quads<C>(re, im, q, j, q1, q2);
-      if (write_u) {
+      for (int j = 0; j < C::R0 / 2; ++j) {
+        T q1[4], q2[4];
+        unpack_quads<C>(re, im, q, j, q1, q2);
         store4<T>(urow + 4 * (size_t)(m1 + C::L1 * j), q1);
         store4<T>(urow + 4 * (size_t)(m2 + C::L1 * j), q2);
       }
-      if constexpr (DIAG) {
-        // np.gradient edge columns: (U[r,1]-U[r,0]) and (U[r,N-1]-U[r,N-2]) live in lane 0
-        if (q == 0 && j == 0 && m1 == 0) {
-          const double d = (double)q1[1] - (double)q1[0];
-          sEdge += d * d;
-        }
-        if (q == 0 && j == C::R0 / 2 - 1 && m1 == 0) {
-          const double d = (double)q2[3] - (double)q2[2];
-          sEdge += d * d;
-        }
-      }
+    }
+  }
+  if constexpr (DIAG) {
+    // np.gradient edge columns: (U[r,1]-U[r,0]) and (U[r,N-1]-U[r,N-2]) live in lane 0
+    if (ls == 0) {
+      T q1[4], q2[4];
+      unpack_quads<C>(re, im, 0, 0, q1, q2);
+      const double d0 = (double)q1[1] - (double)q1[0];
+      unpack_quads<C>(re, im, 0, C::R0 / 2 - 1, q1, q2);
+      const double d1 = (double)q2[3] - (double)q2[2];
+      sEdge += d0 * d0 + d1 * d1;
     }
   }
   if constexpr (DIAG && FUSE) STAMP(0, 3);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (DIAG) {
-    // Row-edge terms of np.gradient (rows 0/1 and N-2/N-1) and Ra of row int(N/2)+1
-    // (solver.py:226-227): only the two or three workgroups that own those rows take this
-    // block-uniform branch; the neighbour row is read back from HBM behind the barrier.
+    // Ra of row int(N/2)+1 (solver.py:226-227): only the workgroup that owns that row takes this
+    // block-uniform branch.  (The row-edge terms of np.gradient -- rows 0/1 and N-2/N-1 -- are
+    // added by the tail, which reads those four rows back from HBM: chs_tail.h.)
     constexpr int RR = C::N / 2 + 1;
-    static_assert(C::C >= 2, "rows 0/1 and N-2/N-1 must share a workgroup");
-    const bool first_blk = (row0 == 0), last_blk = (row0 == C::N - C::C);
     const bool ra_blk = (row0 == (RR / C::C) * C::C);
-    if (first_blk || last_blk || ra_blk) {
-      __syncthreads();  // this workgroup's rows are in memory and visible to its other waves
-      const bool e0 = first_blk && sub == 0, e1 = last_blk && sub == C::C - 1;
-      if (e0 || e1) {
-        const T* other = e0 ? (U + (size_t)C::N) : (U + (size_t)(C::N - 2) * C::N);
-#pragma unroll
-        for (int q = 0; q < C::NP0; ++q) {
-          const int m1 = ls + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-          for (int j = 0; j < C::R0 / 2; ++j) {
-            T q1[4], q2[4], o1[4], o2[4];
-            unpack_quads<C>(re, im, q, j, q1, q2);
-            load4<T>(other + 4 * (size_t)(m1 + C::L1 * j), o1);
-            load4<T>(other + 4 * (size_t)(m2 + C::L1 * j), o2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const double d1 = (double)o1[e] - (double)q1[e], d2 = (double)o2[e] - (double)q2[e];
-              sEdge += d1 * d1 + d2 * d2;
-            }
-          }
-        }
-      }
+    if (ra_blk) {
       // Ra: mean absolute deviation of one row from its own mean (two passes over registers)
       const bool mine = ra_blk && sub == RR % C::C;
       double rs = 0.0;
@@ -459,12 +436,17 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   if constexpr (MODE == MODE_STEP) stagger_start<CHS_STAGGER_COL>();
   if constexpr (MODE == MODE_STEP) STAMP(1, 0);
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
+  int bid = blockIdx.x;
   if constexpr (MODE == MODE_STEP) {
-    // one workgroup beyond the tiles: the record of the PREVIOUS step and this step's time
-    // bookkeeping (chs_fast_step), next to the column pass instead of a launch of its own
-    if (blockIdx.x == C::N / C::C) {
-      step_tail_body<C::THREADS>(ta, st, reinterpret_cast<double*>(chs_dyn_lds));
-      return;
+    // one extra workgroup, dispatched FIRST (block 0) so that its short chain of dependent loads runs
+    // under the first wave of tiles instead of trailing the kernel: the record of the PREVIOUS step
+    // and this step's time bookkeeping (chs_fast_step), instead of a launch of its own
+    if (ta.enabled) {
+      if (bid == 0) {
+        step_tail_body<C::THREADS>(ta, st, reinterpret_cast<double*>(chs_dyn_lds));
+        return;
+      }
+      bid -= 1;
     }
   }
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
@@ -472,9 +454,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // b, b+8, ...: same XCD under round-robin dispatch (speed only, see row_of_block)
   int ct, hh;
   if constexpr (CS::Q == 1) {
-    ct = blockIdx.x; hh = 0;
+    ct = bid; hh = 0;
   } else {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = bid & 7, j = bid >> 3;
     ct = xcd + 8 * (j / CS::Q); hh = j % CS::Q;
   }
   if constexpr (MODE == MODE_STEP) {
@@ -687,7 +669,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     const double acc1[1] = {e2};
     double tot1[1];
     block_sum_store<1, C::THREADS / 64>(acc1, red, tot1);
-    if (threadIdx.x == 0) partE2[blockIdx.x] = tot1[0];
+    if (threadIdx.x == 0) partE2[bid] = tot1[0];
   }
 }
 

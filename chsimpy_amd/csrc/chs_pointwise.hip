@@ -299,6 +299,7 @@ TailArgs chs_tail_args(const Engine* E, int set, int do_pre) {
   ta.partColMin = E->dPartColMin;
   ta.nRow = E->nRowBlocks; ta.nE2 = E->nPartE2; ta.nMu = E->nPartMu; ta.nColMin = E->nColMinBlocks;
   ta.rows = E->dRows; ta.rowsCap = E->rowsCap;
+  ta.U = E->dU; ta.f32 = (E->dtype == CHS_F32) ? 1 : 0;
   return ta;
 }
 

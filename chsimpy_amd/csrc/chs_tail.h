@@ -65,7 +65,7 @@ __device__ __forceinline__ void fin_update(const DevConsts& dc, DevState* st, do
 }
 
 // Inputs of one tail.
-//   partDiag[nRow][4] = {sE, edge-row/column terms, sPS, cSA} and partRa from k_row_inv
+//   partDiag[nRow][4] = {sE, column-edge terms, sPS, cSA} and partRa from k_row_inv
 //   partE2[nE2]       = spectral gradient sums from k_col
 //   partMu[nMu]       = sum(mu^2) of the NEXT step's EnergieEut from k_row_inv (fused)
 struct TailArgs {
@@ -75,6 +75,8 @@ struct TailArgs {
   const double* partDiag = nullptr; const double* partE2 = nullptr; const double* partMu = nullptr;
   const double* partColMin = nullptr; const double* partRa = nullptr;
   int nRow = 0, nE2 = 0, nMu = 0, nColMin = 0;
+  const void* U = nullptr;  // the field of the recorded step: rows 0, 1, N-2, N-1 are read (np.gradient row edges)
+  int f32 = 0;              // element type of U
   double* rows = nullptr;
   long long rowsCap = 0;
 };
@@ -102,6 +104,23 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
     v[3] += ta.partDiag[(size_t)i * 4 + 3];
   }
   for (int i = tid; i < ta.nE2; i += THREADS) v[4] += ta.partE2[i];
+  // one-sided row edges of np.gradient (solver.py:213-217): (U[1,c]-U[0,c])^2 + (U[N-1,c]-U[N-2,c])^2;
+  // the row kernel adds the column edges, k_col the spectral bulk
+  if (ta.U) {
+    const size_t last = (size_t)(N - 2) * N;
+    for (int c = tid; c < N; c += THREADS) {
+      double a0, a1, b0, b1;
+      if (ta.f32) {
+        const float* u = (const float*)ta.U;
+        a0 = u[c]; a1 = u[N + c]; b0 = u[last + c]; b1 = u[last + N + c];
+      } else {
+        const double* u = (const double*)ta.U;
+        a0 = u[c]; a1 = u[N + c]; b0 = u[last + c]; b1 = u[last + N + c];
+      }
+      const double d0 = a1 - a0, d1 = b1 - b0;
+      v[1] += d0 * d0 + d1 * d1;
+    }
+  }
   if (do_pre)
     for (int i = tid; i < ta.nMu; i += THREADS) v[5] += ta.partMu[i];
   if (adapt)
