@@ -402,12 +402,12 @@ struct ColStage {
   static constexpr int ROWS = C::N / 2;        // rows per round
   static constexpr int ELEMS = LINES * LP;     // staging elements
   static constexpr int JR = C::R0 / 4;         // pass-0 half-indices j per round
-  static constexpr int PER = ROWS * C::C / (2 * C::THREADS);  // 16-byte (2-element) pieces per thread per round
+  static constexpr int PW = (C::C % 2 == 0) ? 2 : 1;            // elements per piece (a 16-byte piece when it can be)
+  static constexpr int PER = ROWS * C::C / (PW * C::THREADS);   // pieces per thread per round
   static constexpr int Q = C::CT / C::C;       // workgroups per tile
   static_assert(C::R0 >= 4, "pass-0 radix must be >= 4");
-  static_assert(C::C % 2 == 0, "pieces are moved two elements at a time");
-  static_assert((ROWS * C::C) % (2 * C::THREADS) == 0, "the tile must split evenly over the threads");
-  // global element offset (inside the tile) and LDS offset of piece f = 2*(tid + i*THREADS) of round rho
+  static_assert((ROWS * C::C) % (PW * C::THREADS) == 0, "the tile must split evenly over the threads");
+  // global element offset (inside the tile) and LDS offset of piece f = PW*(tid + i*THREADS) of round rho
   static __device__ __forceinline__ size_t goff(int rho, int f, int h) {
     const int row = f / C::C, c = f % C::C;
     return ((size_t)rho * ROWS + row) * C::CT + h * C::C + c;
@@ -501,13 +501,16 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     // first (one HBM latency for both rounds), then it passes through LDS half by half.
     const T* tile = Tin + (size_t)ct * C::N * C::CT;
     constexpr int PER = CS::PER;
-    T stage[2][2 * PER];
+    constexpr int PW = CS::PW;
+    T stage[2][PW * PER];
     auto request = [&](int rho) {
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        const int f = 2 * (threadIdx.x + i * C::THREADS);
+        const int f = PW * (threadIdx.x + i * C::THREADS);
         const T* src = tile + CS::goff(rho, f, hh);
-        if constexpr (sizeof(T) == 8) {
+        if constexpr (PW == 1) {
+          stage[rho][i] = *src;
+        } else if constexpr (sizeof(T) == 8) {
           const double2 v = *reinterpret_cast<const double2*>(src);
           stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
         } else {
@@ -530,10 +533,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       }
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        const int f = 2 * (threadIdx.x + i * C::THREADS);
+        const int f = PW * (threadIdx.x + i * C::THREADS);
         const int lo = CS::loff(f);
-        lds[lo] = stage[rho][2 * i];
-        lds[lo + 1] = stage[rho][2 * i + 1];
+        lds[lo] = stage[rho][PW * i];
+        if constexpr (PW == 2) lds[lo + 1] = stage[rho][2 * i + 1];
       }
       __syncthreads();
 #pragma unroll
@@ -655,12 +658,16 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       for (int i = 0; i < CS::PER; ++i) {
         // laundered: the staging addresses are recomputed here instead of being kept alive in
         // registers since the stage-in (a spill reload here would wait on every hat_U store)
-        const int f = 2 * (launder((int)threadIdx.x) + i * C::THREADS);
+        const int f = CS::PW * (launder((int)threadIdx.x) + i * C::THREADS);
         const int lo = CS::loff(f);
         T* dst = tile + CS::goff(rho, f, hh);
-        const T a = lds[lo], b = lds[lo + 1];
-        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(a, b);
-        else *reinterpret_cast<float2*>(dst) = make_float2(a, b);
+        if constexpr (CS::PW == 1) {
+          *dst = lds[lo];
+        } else {
+          const T a = lds[lo], b = lds[lo + 1];
+          if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(a, b);
+          else *reinterpret_cast<float2*>(dst) = make_float2(a, b);
+        }
       }
     }
   }
