@@ -166,7 +166,8 @@ def main():
         ms, calls = eng.profile_steps(a.profile_steps)
         names = eng.kernel_names()
         per = {names[i]: ms[i] / calls[i] for i in range(len(names)) if names[i] and calls[i] > 0}
-        dom = max(per, key=per.get)
+        tot = {names[i]: ms[i] for i in range(len(names)) if names[i] and calls[i] > 0}
+        dom = max(tot, key=tot.get)  # dominant = most device time over the profiled steps (not the once-per-call prologue)
         transfers = SLOT_TRANSFERS.get(eng.engine, {}).get(dom)
         if transfers is None:
             # kernels outside the 8-transfer model: price them with the whole-step figure
