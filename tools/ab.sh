@@ -1,13 +1,15 @@
 #!/bin/bash
 # A/B timing of prebuilt library variants on one GPU box (box-to-box clocks differ by a few %):
-#   tools/ab.sh [rounds]   -- runs bench.py with every chsimpy_amd/lib/variants/*.so, interleaved
+#   tools/ab.sh [rounds] [bench args...]  -- runs bench.py with every chsimpy_amd/lib/variants/*.so, interleaved
 rounds=${1:-2}
+shift
+args=${@:---steps 300 --warmup 30}
 mkdir -p gpurun_out
 : > gpurun_out/ab.log
 for r in $(seq $rounds); do
   for v in chsimpy_amd/lib/variants/*.so; do
     cp $v chsimpy_amd/lib/libchs_hip.so
-    timeout -k 10 200 python bench.py --no-cpu-baseline --steps 300 --warmup 30 > gpurun_out/ab_one.log 2>&1 || { echo "$v failed"; tail -5 gpurun_out/ab_one.log; exit 1; }
+    timeout -k 10 200 python bench.py --no-cpu-baseline $args > gpurun_out/ab_one.log 2>&1 || { echo "$v failed"; tail -5 gpurun_out/ab_one.log; exit 1; }
     python - "$v" <<'PY' | tee -a gpurun_out/ab.log
 import json, sys
 d = json.loads(open('gpurun_out/ab_one.log').read().strip().splitlines()[-1])
