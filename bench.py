@@ -40,14 +40,15 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=0, help='0 = size the CPU sample automatically')
     ap.add_argument('--profile-steps', type=int, default=20)
+    ap.add_argument('--energy-stop', action='store_true', help='full_sim=False (the reference default: stop at the E2 maximum); not the headline workload')
     return ap.parse_args()
 
 
-def make_params(N, dtype, engine, device, rank):
+def make_params(N, dtype, engine, device, rank, full_sim=True):
     import chsimpy_amd
     from chsimpy_amd import utils
     p = chsimpy_amd.Parameters()
-    p.N, p.ntmax, p.full_sim, p.kappa_tilde = N, 10 ** 9, True, KAPPA
+    p.N, p.ntmax, p.full_sim, p.kappa_tilde = N, 10 ** 9, full_sim, KAPPA
     p.dtype, p.engine, p.device = dtype, engine, device
     if rank > 0:
         # ensemble member: experiment.py:92-96 scales A0/A1 by factors from PCG64(A_seed)
@@ -120,7 +121,7 @@ def main():
     import chsimpy_amd
 
     N = a.grid
-    p = make_params(N, a.dtype, a.engine, device, rank)
+    p = make_params(N, a.dtype, a.engine, device, rank, not a.energy_stop)
     s = chsimpy_amd.Solver(p)
     s.prepare()
     eng = s._engine
@@ -199,7 +200,7 @@ def main():
             'dtype': 'f64' if esz == 8 else 'f32', 'data': 'synthetic',
             'config': {'workload': f'N={N} {"fp64" if esz == 8 else "fp32"} Cahn-Hilliard timestep loop '
                                    f'(BASELINE.json configs[2] at N=4096), U_init = 0.875 + 0.00875*(PCG64(2023).random - 0.5), '
-                                   f'kappa_tilde={KAPPA}, full_sim',
+                                   f'kappa_tilde={KAPPA}, ' + ('energy stop armed (full_sim=False)' if a.energy_stop else 'full_sim'),
                        'N': N, 'engine': eng.engine,
                        'ensemble': f'{world} independent run(s), one per GPU' if world > 1 else 'single run',
                        'device_ms_per_step': round(dev_ms / a.steps, 5)},

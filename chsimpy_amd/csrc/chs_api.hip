@@ -328,7 +328,18 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   E->lastStepMs = ms;
   DevState s;
   CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
-  if (s.halt) E->hat_valid = false;  // a deferred tail lets k_col run once past the stop (chs_fast_step)
+  if (s.halt && s.stop_reason == CHS_STOP_ENERGY && !s.nan_flag && fused && !E->storeU && s.rows_written < nsteps) {
+    // the energy rule ended the call before its last step and the row kernel has been keeping U in
+    // registers: hat_U is that of the stopping step, rebuild the field from it (solver.py:242-251
+    // returns the U of the stopping step)
+    DevState r = s;
+    r.halt = 0;
+    CHS_HIP(hipMemcpy(E->dState, &r, sizeof r, hipMemcpyHostToDevice));
+    if ((rc = chs_fast_recover_u(E))) return rc;
+    CHS_HIP(hipStreamSynchronize(E->stream));
+    CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
+  }
+  if (s.halt) E->hat_valid = false;  // (a deferred tail lets k_col run once past a NaN stop)
   int64_t done = s.rows_written;
   if (done > nsteps) done = nsteps;
   if (steps_done) *steps_done = done;

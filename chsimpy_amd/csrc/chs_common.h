@@ -228,6 +228,7 @@ int chs_direct_dct2d(Engine* E, const void* in, void* out, void* tmp, bool inver
 
 // ---- fast engine (chs_fast.hip) ---------------------------------------------
 bool chs_fast_supported(int N, int dtype);
+int chs_fast_recover_u(Engine* E);  // U <- idctn(hat_U): the field of the last completed step
 int chs_fast_init(Engine* E);
 void chs_fast_free(Engine* E);
 int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse);  // natural in/out (tests)

@@ -58,7 +58,7 @@ extern "C" int chs_debug_stamps(int which, unsigned long long* out, int n) {
 #include "chs_tail.h"
 #include "chs_math.h"
 
-enum { MODE_STEP = 0, MODE_FWD_NATIVE = 1, MODE_FWD_NATURAL = 2, MODE_INV_NATURAL = 3 };
+enum { MODE_STEP = 0, MODE_FWD_NATIVE = 1, MODE_FWD_NATURAL = 2, MODE_INV_NATURAL = 3, MODE_INV_NATIVE = 4 };
 
 template <class C>
 __device__ __forceinline__ size_t tile_addr(int r, int k) {
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   T* hpark1 = lds + col_lds_elems<C>() + threadIdx.x;
   T* hpark2 = lds + threadIdx.x;
   T hearly[PARK ? C::E : 1];
-  if constexpr (MODE != MODE_INV_NATURAL) {
+  if constexpr (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE) {
     // ---- stage in: tile rows -> quads of this group's column.  The whole tile is requested
     // first (one HBM latency for both rounds), then it passes through LDS half by half.
     const T* tile = Tin + (size_t)ct * C::N * C::CT;
@@ -576,8 +576,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // ---- recombination / spectral stage / adjoint recombination, in place per slot
   double e2 = 0.0;
   T h00 = T(0);
-  constexpr bool FWD = (MODE != MODE_INV_NATURAL);
-  constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL);
+  constexpr bool FWD = (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE);
+  constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL || MODE == MODE_INV_NATIVE);
   if constexpr (MODE == MODE_STEP) {
     recombine<C, true, true, CHS_COL_PIPE>(re, im, tb, l, fetch,
       [&](int pbase, const int*, T y[4], bool live, const Fetched& p) {
@@ -616,6 +616,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
           if (live) hcol[hp] = y[t];
         } else if constexpr (MODE == MODE_FWD_NATURAL) {
           if (live) nat[(size_t)kr * C::N + kc] = y[t];
+        } else if constexpr (MODE == MODE_INV_NATIVE) {
+          y[t] = hcol[hp];  // hat_U as MODE_STEP left it: the column half of U = idctn(hat_U)
         } else {
           y[t] = nat[(size_t)kr * C::N + kc];
         }
@@ -730,6 +732,7 @@ struct Launch {
     if ((rc = set_lds(k_col<CC, MODE_FWD_NATIVE>, col_lds))) return rc;
     if ((rc = set_lds(k_col<CC, MODE_FWD_NATURAL>, col_lds))) return rc;
     if ((rc = set_lds(k_col<CC, MODE_INV_NATURAL>, col_lds))) return rc;
+    if ((rc = set_lds(k_col<CC, MODE_INV_NATIVE>, col_lds))) return rc;
     return CHS_OK;
   }
   static int row_fwd(Engine* E, const void* in, void* out, bool pointwise) {
@@ -779,6 +782,9 @@ struct Launch {
         break;
       case MODE_FWD_NATURAL:
         k_col<CC, MODE_FWD_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
+        break;
+      case MODE_INV_NATIVE:
+        k_col<CC, MODE_INV_NATIVE><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
         break;
       default:
         k_col<CC, MODE_INV_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
@@ -976,6 +982,15 @@ int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse) {
   return P->row_inv(E, ROW_INV_PLAIN, E->dT1, out, nullptr);
 }
 
+// U <- idctn(hat_U) from k_col's native order: the field of the last completed step when the fused
+// row kernel has not been writing U (chs_fast_step) and a stop ended the call early.
+int chs_fast_recover_u(Engine* E) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  int rc;
+  if ((rc = P->col(E, MODE_INV_NATIVE, nullptr, E->dT1, E->dHat, nullptr))) return rc;
+  return P->row_inv(E, ROW_INV_PLAIN, E->dT1, E->dU, nullptr);
+}
+
 // hat_U <- dctn(U) in k_col's native order (solver.py:159)
 int chs_fast_enter(Engine* E) {
   FastPlan* P = (FastPlan*)E->dTw;
@@ -1008,23 +1023,27 @@ int chs_fast_prologue(Engine* E) {
 // EnergieEut(U_k) and partMu its sum of squares; on exit U_(k+1) is in HBM, the pointwise
 // diagnostics partials of U_(k+1) are ready for k_fin and, with fuse_next, T1/partMu are
 // ready for the next step.
-// With a fixed time step and no time limit the tail of step s decides nothing the column pass of
-// step s+1 needs: it is deferred and rides as one extra workgroup in k_col of step s+1 -- no launch
-// of its own, nothing waits for it.  A stop it raises (energy rule, NaN) takes effect one kernel
-// later: k_col of step s+1 has then advanced hat_U and T2 once more, which nothing reads again
-// (k_row_inv sees `halt` and leaves U alone; hat_U is re-derived from U on the next call, as in
-// solver.py:159 -- run_steps drops hat_valid).  The partial sums alternate between two sets.
+// full_sim, fixed time step, no time limit: the tail of step s decides nothing the column pass of
+// step s+1 needs.  It is deferred and rides as one extra workgroup in k_col of step s+1 -- no launch
+// of its own, nothing waits for it.  Only NaN can stop such a run (one kernel later; the field is
+// unspecified then anyway).  The partial sums alternate between two sets.
 static bool can_defer_tail(const Engine* E) {
-  return !E->dc.adaptive_time && !(E->dc.time_limit_s > 0.0) && !E->timer.on && E->partSet[0][0] != nullptr;
+  return !E->dc.adaptive_time && !(E->dc.time_limit_s > 0.0) && E->dc.full_sim && !E->timer.on &&
+         E->partSet[0][0] != nullptr;
+}
+// Fixed time step, no time limit: between the steps of a call nothing reads U from HBM, so the fused
+// row kernel keeps it in registers.  With the energy rule armed (full_sim = 0, the reference default)
+// the tail runs in stream order right behind the row kernel; when it stops the run, hat_U is still
+// that of the stopping step and run_steps() rebuilds U = idctn(hat_U) once (chs_fast_recover_u).
+static bool can_skip_u(const Engine* E) {
+  return !E->dc.adaptive_time && !(E->dc.time_limit_s > 0.0) && !CHS_ALWAYS_STORE_U;
 }
 
 int chs_fast_step(Engine* E, bool first, bool last) {
   FastPlan* P = (FastPlan*)E->dTw;
   int rc;
   const bool defer = can_defer_tail(E);
-  // U between the steps of a call: nobody reads it unless a stop can end the call early (then the
-  // U of the stopping step is what the caller gets, solver.py:242-251) or the adaptive step sweeps it
-  E->storeU = E->dc.adaptive_time || (E->dc.time_limit_s > 0.0) || !E->dc.full_sim || CHS_ALWAYS_STORE_U;
+  E->storeU = !can_skip_u(E);
   select_partial_set(E);
   if (first) {
     // time-step control of the first step of the call; later steps get it from the tail.
