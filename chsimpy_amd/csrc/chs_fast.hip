@@ -830,10 +830,16 @@ using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, 2, 1, 16, CH
 #define CHS_G8192C_WPS 2
 #endif
 // N = 8192 fp32: four wavefronts per transform, 16 complex values per lane, four radix-8 passes
-using G8192 = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, 4>;
+#ifndef CHS_G8192_THREADS
+#define CHS_G8192_THREADS 512
+#endif
+using G8192 = FCfg<float, 8192, 256, CHS_G8192_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, 4>;
 using G8192C = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS, 4>;
-using G4096 = FCfg<float, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 4, 4>;
-using G4096C = FCfg<float, 4096, 128, 512, 8, 4, 8, 8, 2, 1, 16, 2, 4>;
+#ifndef CHS_G4096_THREADS
+#define CHS_G4096_THREADS 256
+#endif
+using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, 4>;
+using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, 4>;
 
 template <class C, class CC = C>
 static void bind(FastPlan* P) {
