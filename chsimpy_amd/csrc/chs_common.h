@@ -166,6 +166,7 @@ struct Engine {
   double* dPartMuAux = nullptr; // scratch partials of the column-sum-only sweep
   int nDiagBlocks = 0;
   int nColMinBlocks = 0;
+  int nColMinCur = 0;  // entries of dPartColMin the last column-sum launch wrote
 
   // deferred tail: the bookkeeping of step s rides as one extra workgroup in k_col of step s+1;
   // the partial sums ping-pong between two sets so that step s+1 does not overwrite what it reads
@@ -173,6 +174,8 @@ struct Engine {
   int parity = 0;
   bool tailDeferred = false;  // the tail of the previous step is still to run
   unsigned stepCount = 0;     // k_col<MODE_STEP> launches so far (tile walk direction alternates)
+  bool fusedAdapt = false;    // the fused row kernel adds up the adaptive-step integrand itself
+  double* dPartColRows = nullptr;  // [nRowBlocks][N] partial column sums of that integrand
   bool storeU = true;         // the fused row kernel writes U on intermediate steps (chs_fast_step)
   int tailSet = 0;            // ... on this partial set
   hipEvent_t evA = nullptr, evB = nullptr;
@@ -208,7 +211,8 @@ enum {
 
 // ---- pointwise / reduction launchers (chs_pointwise.hip) -------------------
 int chs_launch_mu(Engine* E);                 // dU -> dMU, partials
-int chs_launch_mu_colsums(Engine* E, int cs_offset);  // dU -> column-sum minimum of the adaptive-step integrand only
+int chs_launch_mu_colsums(Engine* E, int cs_offset);
+int chs_launch_colmin_rows(Engine* E, int cs_offset);  // min over the columns of sum(dPartColRows)  // dU -> column-sum minimum of the adaptive-step integrand only
 struct TailArgs;
 TailArgs chs_tail_args(const Engine* E, int set, int do_pre);  // set < 0: the current partial-sum pointers
 int chs_launch_step_tail(Engine* E, int do_pre);  // fused pipeline: record of step s + time-step control of step s+1

@@ -19,6 +19,7 @@
 // kc*N + p*G + l -- nobody else reads it.
 #include <cmath>
 #include <vector>
+#include <cstdlib>
 
 #include "chs_common.h"
 #ifdef CHS_STAMPS
@@ -236,12 +237,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
 #ifndef CHS_LB_COL
 #define CHS_LB_COL 2
 #endif
-template <class C, bool DIAG, bool FUSE>
+template <class C, bool DIAG, bool FUSE, bool ADAPT = false>
 __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
                                                     typename C::T* __restrict__ T1, FTables<typename C::T> tb,
                                                     DevConsts dc, const DevState* __restrict__ st,
                                                     double* __restrict__ partDiag, double* __restrict__ partMu,
-                                                    double* __restrict__ partRa, int store_u) {
+                                                    double* __restrict__ partRa, int store_u,
+                                                    double* __restrict__ partColRows = nullptr) {
   using T = typename C::T;
   __shared__ double red[64];
   if (st->halt) return;
@@ -354,6 +356,54 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     }
     if (bad) sE = __builtin_nan("");  // U left (0,1): the record of this step becomes NaN
     acc[0] = sE; acc[1] = sEdge; acc[2] = sPS; acc[3] = cSA; acc[4] = s2;
+  }
+  if constexpr (ADAPT) {
+    // Adaptive step (solver.py:177-183): on the steps whose successor re-evaluates delt, the column
+    // sums of delt_max/sqrt(1 + alpha*mu^2) are needed.  mu of the next step is in the registers
+    // right now: every workgroup adds up its rows per column (through the idle exchange scratch) and
+    // writes one partial row; k_colmin sums the partial rows and takes the minimum.  No sweep of U.
+    // NH passes over the columns when a row of doubles does not fit the scratch (fp32 transforms)
+    constexpr int LDSB = C::C * C::SCR * (int)sizeof(T);
+    constexpr int NH = (C::C == 1 || C::N * 8 <= LDSB) ? 1 : 2;
+    constexpr int JH = (C::R0 / 2) / NH;  // quads j*L1 .. (j+1)*L1 cover a quarter (R0 = 8) of the columns each
+    static_assert(!ADAPT || (FUSE && C::C <= 4 && (C::C == 1 || C::N * 8 / NH <= LDSB) && (C::R0 / 2) % NH == 0),
+                  "partial column sums need the scratch");
+    const long long cs = st->computed_steps + 1;  // the record of this step has not advanced it yet
+    if (cs > 500 && (cs % 2) == 0) {              // (uniform) cf. k_mu's want_col
+      const int lg = launder(l);
+      double* prow = partColRows + (size_t)blockIdx.x * C::N;
+      double* gl = reinterpret_cast<double*>(chs_dyn_lds);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int s = C::C - 1; s >= 0; --s) {
+          __syncthreads();
+          if (sub == s) {
+#pragma unroll
+            for (int q = 0; q < C::NP0; ++q) {
+              const int m1 = lg + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+              for (int j = h * JH; j < (h + 1) * JH; ++j) {
+                T q1[4], q2[4];
+                unpack_quads<C>(re, im, q, j, q1, q2);  // mu of row `row`, columns 4*(m + L1*j) .. +3
+                const int c1 = 4 * (m1 + C::L1 * j), c2 = 4 * (m2 + C::L1 * j);
+                const int o1 = c1 - h * (C::N / NH), o2 = c2 - h * (C::N / NH);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  double g1 = chs_dt_integrand((double)q1[e], dc.delt_max);
+                  double g2 = chs_dt_integrand((double)q2[e], dc.delt_max);
+                  if (s < C::C - 1) { g1 += gl[o1 + e]; g2 += gl[o2 + e]; }
+                  if (s > 0) { gl[o1 + e] = g1; gl[o2 + e] = g2; }
+                  else { prow[c1 + e] = g1; prow[c2 + e] = g2; }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one quad pair at a time: no pile-up of addresses and operands
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();  // the scratch goes back to the forward passes
+    }
   }
   if constexpr (DIAG && FUSE) STAMP(0, 4);
   if constexpr (FUSE) {
@@ -685,7 +735,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-enum { ROW_INV_PLAIN = 0, ROW_INV_DIAG = 1, ROW_INV_FUSED = 2 };
+enum { ROW_INV_PLAIN = 0, ROW_INV_DIAG = 1, ROW_INV_FUSED = 2, ROW_INV_FUSED_ADAPT = 3 };
 
 struct FastPlan {
   int N, G, R0, RA, RB, RL, threads, col_tiles;
@@ -711,6 +761,8 @@ template <class C, class CC = C>
 struct Launch {
   using T = typename C::T;
   static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T);
+  // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
+  static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && C::R0 == 8;
   // + the parking area of half a hat_U column per lane (k_col<MODE_STEP>)
   static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (CHS_COL_PARK ? (size_t)CC::E * CC::THREADS : 0)) * sizeof(T) + CHS_COL_LDS_PAD;
   static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
@@ -728,6 +780,10 @@ struct Launch {
     if ((rc = set_lds(k_row_inv<C, false, false>, row_lds))) return rc;
     if ((rc = set_lds(k_row_inv<C, true, false>, row_lds))) return rc;
     if ((rc = set_lds(k_row_inv<C, true, true>, row_lds))) return rc;
+    if constexpr (ADAPT_OK) {
+      if ((rc = set_lds(k_row_inv<C, true, true, true>, row_lds))) return rc;
+    }
+    E->fusedAdapt = ADAPT_OK && getenv("CHS_ADAPT_SWEEP") == nullptr;  // CHS_ADAPT_SWEEP=1: keep the separate sweep of U
     if ((rc = set_lds(k_col<CC, MODE_STEP>, col_lds))) return rc;
     if ((rc = set_lds(k_col<CC, MODE_FWD_NATIVE>, col_lds))) return rc;
     if ((rc = set_lds(k_col<CC, MODE_FWD_NATURAL>, col_lds))) return rc;
@@ -755,9 +811,15 @@ struct Launch {
     else if (mode == ROW_INV_DIAG)
       k_row_inv<C, true, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
                                                                    E->dPartDiag, E->dPartMu, E->dPartRa, 1);
-    else
+    else if (mode == ROW_INV_FUSED)
       k_row_inv<C, true, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
                                                                   E->dPartDiag, E->dPartMu, E->dPartRa, E->storeU ? 1 : 0);
+    else {
+      if constexpr (ADAPT_OK)
+        k_row_inv<C, true, true, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
+                                                                          E->dPartDiag, E->dPartMu, E->dPartRa, E->storeU ? 1 : 0, E->dPartColRows);
+      else { chs_set_error("fused adaptive row kernel is not built for this configuration"); return CHS_EINVAL; }
+    }
     CHS_HIP(hipGetLastError());
     return CHS_OK;
   }
@@ -955,6 +1017,8 @@ int chs_fast_init(Engine* E) {
   CHS_HIP(hipMalloc(&E->partSet[1][1], sizeof(double) * (size_t)(E->nBands > E->N ? E->nBands : E->N)));
   CHS_HIP(hipMalloc(&E->partSet[1][2], sizeof(double) * (size_t)E->nPartE2));
   CHS_HIP(hipMalloc(&E->partSet[1][3], sizeof(double) * 8));
+  if (E->dc.adaptive_time && E->fusedAdapt)
+    CHS_HIP(hipMalloc(&E->dPartColRows, sizeof(double) * (size_t)E->nRowBlocks * E->N));
   return CHS_OK;
 }
 
@@ -969,6 +1033,8 @@ void chs_fast_free(Engine* E) {
     E->dPartE2 = E->partSet[0][2]; E->dPartRa = E->partSet[0][3];
     for (int i = 0; i < 4; ++i) { hipFree(E->partSet[1][i]); E->partSet[1][i] = nullptr; E->partSet[0][i] = nullptr; }
   }
+  if (E->dPartColRows) hipFree(E->dPartColRows);
+  E->dPartColRows = nullptr;
   if (E->dPartE2) hipFree(E->dPartE2);
   if (E->dPartRa) hipFree(E->dPartRa);
   E->dPartRa = nullptr;
@@ -1041,8 +1107,11 @@ static bool can_defer_tail(const Engine* E) {
 // row kernel keeps it in registers.  With the energy rule armed (full_sim = 0, the reference default)
 // the tail runs in stream order right behind the row kernel; when it stops the run, hat_U is still
 // that of the stopping step and run_steps() rebuilds U = idctn(hat_U) once (chs_fast_recover_u).
+static bool fused_adaptive(const Engine* E) {
+  return E->dc.adaptive_time && E->fusedAdapt && E->dPartColRows != nullptr;
+}
 static bool can_skip_u(const Engine* E) {
-  return !E->dc.adaptive_time && !(E->dc.time_limit_s > 0.0) && !CHS_ALWAYS_STORE_U;
+  return (!E->dc.adaptive_time || fused_adaptive(E)) && !(E->dc.time_limit_s > 0.0) && !CHS_ALWAYS_STORE_U;
 }
 
 int chs_fast_step(Engine* E, bool first, bool last) {
@@ -1069,13 +1138,14 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   E->tailDeferred = false;
   if (rc) return rc;
   chs_slot_begin(E, SLOT_INV);
-  rc = P->row_inv(E, last ? ROW_INV_DIAG : ROW_INV_FUSED, T2, E->dU, E->dT1);
+  const bool fa = fused_adaptive(E);
+  rc = P->row_inv(E, last ? ROW_INV_DIAG : (fa ? ROW_INV_FUSED_ADAPT : ROW_INV_FUSED), T2, E->dU, E->dT1);
   chs_slot_end(E, SLOT_INV);
   if (rc) return rc;
   if (!last && E->dc.adaptive_time) {
     // column sums of the adaptive-step integrand of the NEXT step (solver.py:183); the record of
     // this step has not advanced computed_steps yet, hence the offset
-    if ((rc = chs_launch_mu_colsums(E, 1))) return rc;
+    if ((rc = fa ? chs_launch_colmin_rows(E, 1) : chs_launch_mu_colsums(E, 1))) return rc;
   }
   if (last || !defer) return chs_launch_step_tail(E, last ? 0 : 1);
   E->tailDeferred = true;

@@ -297,7 +297,7 @@ TailArgs chs_tail_args(const Engine* E, int set, int do_pre) {
   ta.partE2 = pp ? E->partSet[set][2] : E->dPartE2;
   ta.partRa = pp ? E->partSet[set][3] : E->dPartRa;
   ta.partColMin = E->dPartColMin;
-  ta.nRow = E->nRowBlocks; ta.nE2 = E->nPartE2; ta.nMu = E->nPartMu; ta.nColMin = E->nColMinBlocks;
+  ta.nRow = E->nRowBlocks; ta.nE2 = E->nPartE2; ta.nMu = E->nPartMu; ta.nColMin = E->nColMinCur ? E->nColMinCur : E->nColMinBlocks;
   ta.rows = E->dRows; ta.rowsCap = E->rowsCap;
   ta.U = E->dU; ta.f32 = (E->dtype == CHS_F32) ? 1 : 0;
   return ta;
@@ -337,7 +337,7 @@ int chs_pointwise_alloc(Engine* E) {
   CHS_HIP(hipMalloc(&E->dPartMuAux, sizeof(double) * (size_t)E->nBands));
   CHS_HIP(hipMalloc(&E->dPartDiag, sizeof(double) * 4 * (size_t)(E->nDiagBlocks > N ? E->nDiagBlocks : N)));
   CHS_HIP(hipMalloc(&E->dPartSum, sizeof(double) * (size_t)E->nBands));
-  CHS_HIP(hipMalloc(&E->dPartColMin, sizeof(double) * (size_t)E->nColMinBlocks));
+  CHS_HIP(hipMalloc(&E->dPartColMin, sizeof(double) * (size_t)((N + 31) / 32)));  // k_colmin: N/256 entries, k_colmin_rows: N/32
   CHS_HIP(hipMalloc(&E->dPartCol, sizeof(double) * (size_t)E->nBands * N));
   return CHS_OK;
 }
@@ -368,6 +368,47 @@ int chs_launch_mu_colsums(Engine* E, int cs_offset) {
                                                            E->dPartMuAux, E->dPartCol, 1, cs_offset)));
   k_colmin<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dPartCol, E->nBands, E->N, E->dState,
                                                             E->dc.adaptive_time, E->dPartColMin, cs_offset);
+  E->nColMinCur = E->nColMinBlocks;
+  chs_slot_end(E, SLOT_MISC);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
+// k_colmin_rows: the same for the partial rows the fused row kernel writes (one per workgroup: up to
+// N/2 of them).  A block owns 32 columns; 8 thread groups stride the rows, LDS adds them up.
+// Writes to partColMin[nColMinBlocks + blockIdx.x] (the second part of the buffer).
+#define CMR_COLS 32
+__global__ __launch_bounds__(PW_THREADS) void k_colmin_rows(const double* __restrict__ partRows, int nRows, int N,
+                                                            const DevState* __restrict__ st, int adaptive,
+                                                            double* __restrict__ partColMin, int cs_offset) {
+  __shared__ double acc[PW_THREADS];
+  if (st->halt) return;
+  const long long cs = st->computed_steps + cs_offset;
+  if (!(adaptive && cs > 500 && (cs % 2) == 0)) return;
+  constexpr int RG = PW_THREADS / CMR_COLS;
+  const int cx = threadIdx.x % CMR_COLS, ry = threadIdx.x / CMR_COLS;
+  const int c = blockIdx.x * CMR_COLS + cx;
+  double s = 0.0;
+  if (c < N)
+    for (int r = ry; r < nRows; r += RG) s += partRows[(size_t)r * N + c];
+  acc[threadIdx.x] = s;
+  __syncthreads();
+  if (ry == 0) {
+    double t = acc[cx];
+    for (int g = 1; g < RG; ++g) t += acc[g * CMR_COLS + cx];
+    if (c >= N) t = 1.0e300;
+    // minimum over the block's 32 columns (they sit in the first half of wave 0)
+    for (int off = 16; off > 0; off >>= 1) t = fmin(t, __shfl_down(t, off, 64));
+    if (cx == 0) partColMin[blockIdx.x] = t;
+  }
+}
+
+int chs_launch_colmin_rows(Engine* E, int cs_offset) {
+  chs_slot_begin(E, SLOT_MISC);
+  const int nb = (E->N + CMR_COLS - 1) / CMR_COLS;
+  k_colmin_rows<<<nb, PW_THREADS, 0, E->stream>>>(E->dPartColRows, E->nRowBlocks, E->N, E->dState,
+                                                   E->dc.adaptive_time, E->dPartColMin, cs_offset);
+  E->nColMinCur = nb;
   chs_slot_end(E, SLOT_MISC);
   CHS_HIP(hipGetLastError());
   return CHS_OK;

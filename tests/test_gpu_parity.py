@@ -314,6 +314,41 @@ def test_fp32_dctn(gpu, N):
     s.close()
 
 
+@pytest.mark.parametrize("N,dmax,dtype", [(2048, 2.4e-10, 'float64'), (4096, 1.2e-10, 'float64'),
+                                           (4096, 1.2e-10, 'float32'), (8192, 6e-11, 'float32')])
+def test_fused_adaptive_column_sums_match_the_sweep(gpu, N, dmax, dtype):
+    """Adaptive dt on the fast engine: the fused row kernel adds up the integrand of solver.py:183 per
+    column itself (no sweep of U, U not written between steps).  CHS_ADAPT_SWEEP=1 keeps the
+    separate sweep kernel (the path the N=64 golden test and the oracle pin): same delt history."""
+    nt = 540
+    runs = {}
+    for mode in ('sweep', 'fused'):
+        if mode == 'sweep':
+            os.environ['CHS_ADAPT_SWEEP'] = '1'
+        else:
+            os.environ.pop('CHS_ADAPT_SWEEP', None)
+        try:
+            p = make(N, nt, 'fast', adaptive_time=True, delt_max=dmax, dtype=dtype)
+            s = chsimpy_amd.Solver(p)
+            s.prepare()
+            sol = s.solve_or_resume(300)      # chunked: the first step of a call sweeps U in both modes
+            sol = s.solve_or_resume(nt - 300)
+            runs[mode] = (sol.U.copy(), sol.timedata.data().copy())
+            s.close()
+        finally:
+            os.environ.pop('CHS_ADAPT_SWEEP', None)
+    Us, ts = runs['sweep']
+    Uf, tf = runs['fused']
+    assert ts.shape == tf.shape == (nt, 9)
+    assert len(np.unique(ts[:, 8])) > 3                        # the step size adapts after step 500
+    # fp32: the sweep recomputes mu from the stored field with another (equally rounded) formula than
+    # the fused kernel's shared-log one, so the two agree to fp32 rounding amplified over the steps
+    tol = 1e-9 if dtype == 'float64' else 2e-4
+    assert np.allclose(tf[:, 8], ts[:, 8], rtol=1e-12 if dtype == 'float64' else 1e-4, atol=0), relerr(tf[:, 8], ts[:, 8])   # delt history
+    assert np.allclose(tf[:, 1:3], ts[:, 1:3], rtol=tol, atol=0)
+    assert np.allclose(Uf, Us, rtol=tol, atol=0), relerr(Uf, Us)
+
+
 def test_fp32_adaptive_vs_fp64_n4096(gpu):
     # The reference's dynamic step is a column SUM (np.linalg.norm(.., ord=-1), solver.py:183), so it
     # grows with N: with the default delt_max the step explodes at N=4096 (NaN at step 506, which the
