@@ -328,10 +328,10 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   E->lastStepMs = ms;
   DevState s;
   CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
-  if (s.halt && s.stop_reason == CHS_STOP_ENERGY && !s.nan_flag && fused && !E->storeU && s.rows_written < nsteps) {
-    // the energy rule ended the call before its last step and the row kernel has been keeping U in
-    // registers: hat_U is that of the stopping step, rebuild the field from it (solver.py:242-251
-    // returns the U of the stopping step)
+  if (s.halt && s.stop_reason != CHS_STOP_NONE && !s.nan_flag && fused && !E->storeU && s.rows_written < nsteps) {
+    // the energy rule or the time limit ended the call before its last step and the row kernel has
+    // been keeping U in registers: hat_U is that of the last completed step, rebuild the field from
+    // it (solver.py:197-199 breaks before U is updated, 242-251 returns the U of the stopping step)
     DevState r = s;
     r.halt = 0;
     CHS_HIP(hipMemcpy(E->dState, &r, sizeof r, hipMemcpyHostToDevice));

@@ -1103,15 +1103,16 @@ static bool can_defer_tail(const Engine* E) {
   return !E->dc.adaptive_time && !(E->dc.time_limit_s > 0.0) && E->dc.full_sim && !E->timer.on &&
          E->partSet[0][0] != nullptr;
 }
-// Fixed time step, no time limit: between the steps of a call nothing reads U from HBM, so the fused
-// row kernel keeps it in registers.  With the energy rule armed (full_sim = 0, the reference default)
-// the tail runs in stream order right behind the row kernel; when it stops the run, hat_U is still
-// that of the stopping step and run_steps() rebuilds U = idctn(hat_U) once (chs_fast_recover_u).
+// Between the steps of a call nothing reads U from HBM (the adaptive step included, once the fused
+// row kernel adds up its integrand), so the fused row kernel keeps it in registers.  Whenever a stop
+// can end the call early (energy rule, time limit) the tail runs in stream order right behind the
+// row kernel: hat_U is then still that of the last completed step and run_steps() rebuilds
+// U = idctn(hat_U) once (chs_fast_recover_u).
 static bool fused_adaptive(const Engine* E) {
   return E->dc.adaptive_time && E->fusedAdapt && E->dPartColRows != nullptr;
 }
 static bool can_skip_u(const Engine* E) {
-  return (!E->dc.adaptive_time || fused_adaptive(E)) && !(E->dc.time_limit_s > 0.0) && !CHS_ALWAYS_STORE_U;
+  return (!E->dc.adaptive_time || fused_adaptive(E)) && !CHS_ALWAYS_STORE_U;
 }
 
 int chs_fast_step(Engine* E, bool first, bool last) {

@@ -121,10 +121,10 @@ int chs_prepare(chs_handle h, double row0[9]);
  * to and including the NaN row are still returned, the field is unspecified then
  * (the reference raises before it assigns solution.U, solver.py:251).
  * The device keeps the field of intermediate steps in registers where nothing can
- * observe it (fixed time step, no time limit); chs_get_U after the call returns the
- * field of the last completed step in every mode -- also after an energy stop, where
- * it is rebuilt from hat_U -- exactly as `self.solution.U = U` after the reference's
- * loop (solver.py:242-251). */
+ * observe it; chs_get_U after the call returns the field of the last completed step
+ * in every mode -- also after an energy or time-limit stop, where it is rebuilt from
+ * hat_U -- exactly as `self.solution.U = U` after the reference's loop
+ * (solver.py:197-199, 242-251). */
 int chs_step_n(chs_handle h, int64_t nsteps, int32_t flags, double* rows, int64_t* steps_done);
 /* flags for chs_step_n */
 #define CHS_STEP_CARRY_HAT 1 /* do not re-derive hat_U on entry: continue the loop of the

@@ -191,6 +191,18 @@ def test_time_limit_stop(gpu):
     assert sol.stop_reason == 'time-limit' and sol.computed_steps < 40
 
 
+def test_time_limit_stop_fast_engine(gpu):
+    """The same on the fused pipeline (N=128): U is not written between steps there, the field of the
+    last completed step is rebuilt from hat_U when the limit ends the call (solver.py:197-199)."""
+    p = make(128, 500, 'fast', time_max=30 * 3e-8 / 1.71e-8 / 60)
+    sol, o = compare_run(p, dict(time_max=p.time_max))
+    assert sol.stop_reason == 'time-limit' and sol.computed_steps < 40
+    # ... and with the energy rule armed as well
+    p = make(128, 500, 'fast', time_max=30 * 3e-8 / 1.71e-8 / 60, full_sim=False)
+    sol, o = compare_run(p, dict(time_max=p.time_max, full_sim=False))
+    assert sol.stop_reason == 'time-limit'
+
+
 def test_adaptive_time(gpu):
     """adaptive_time beyond step 500 (solver.py:177-193) against the golden delt history."""
     g = np.load(os.path.join(GOLD, 'n64_adaptive_600.npz'))
