@@ -143,6 +143,9 @@ __device__ __forceinline__ void stagger_start() {
 #ifndef CHS_COL_ZIGZAG
 #define CHS_COL_ZIGZAG 1
 #endif
+#ifndef CHS_LOG_TABLE
+#define CHS_LOG_TABLE 1  // table-driven log in the fused row kernel's pointwise part (0: division-based)
+#endif
 // ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
 #ifndef CHS_COL_PARK
 #define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
@@ -251,6 +254,12 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
   if constexpr (DIAG && FUSE) stagger_start<CHS_STAGGER_ROW>();
   const double mean_u = st->meanU;  // requested at entry (k_col of this step wrote it), used in the pointwise part
+  // reduction table of the table-driven log, behind the exchange scratch (visible after the first barrier)
+  double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
+  if constexpr (DIAG && CHS_LOG_TABLE && sizeof(T) == 8) {
+    for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
+    if constexpr (C::WAVE_LOCAL) __syncthreads();  // (no block barrier before the pointwise part otherwise)
+  }
   const int row0 = row_of_block<C>(blockIdx.x);
   const int row = row0 + sub;
   T* scr = lds + (size_t)sub * C::SCR;
@@ -332,7 +341,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     auto point = [&](T& u) {
       const T uinv = T(1) - u;
       bad |= ((u > T(0)) && (uinv > T(0))) ? 0 : 1;
-      const T lU = chs_log_pos<T>(u), lV = chs_log_pos<T>(uinv);
+      T lU, lV;
+      if constexpr (CHS_LOG_TABLE) { lU = chs_log_pos_tab<T>(u, ltab); lV = chs_log_pos_tab<T>(uinv, ltab); }
+      else { lU = chs_log_pos<T>(u); lV = chs_log_pos<T>(uinv); }
       sE += (double)chs_energy_from_logs_fast<T>(u, uinv, lU, lV, RT, B, A0, A1);
       sPS += fabs((double)u - mean);
       cSA += ((double)u < thr) ? 1.0 : 0.0;
@@ -760,7 +771,7 @@ static FTables<T> get_tables(Engine* E) {
 template <class C, class CC = C>
 struct Launch {
   using T = typename C::T;
-  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T);
+  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0);
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
   static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && C::R0 == 8;
   // + the parking area of half a hat_U column per lane (k_col<MODE_STEP>)

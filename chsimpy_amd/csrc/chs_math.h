@@ -111,9 +111,40 @@ __device__ __forceinline__ double chs_log_ratio_f64(double a, double b) {
   return ok ? res : __builtin_nan("");  // every non-finite case ends in the NaN assertion anyway
 }
 
+// Table-driven log for x > 0 (no division): x = 2^e m, m in [sqrt(1/2), sqrt(2)); i = rint(256 m);
+// r = fma(m, rc_i, -1) with rc_i = fl(256/i) from the table (|r| <= 2.8e-3);
+// log x = (e ln2_hi + lc_i) + (e ln2_lo + log1p(r)), lc_i = fl(-log rc_i), log1p by its series to r^7
+// (truncation r^7/8 < 2e-19 relative).  `tab` = chs_log_table copied to LDS.  21 VALU + one LDS read
+// against 27 incl. a quarter-rate reciprocal for chs_log_pos_f64; same accuracy class (test_gpu_math).
+#include "chs_log_table.h"
+__device__ __forceinline__ double chs_log_pos_tab_f64(double x, const double2* tab) {
+#pragma clang fp contract(off)
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const int c = (m < CHS_SQRT1_2) ? 1 : 0;
+  m = __builtin_ldexp(m, c);                  // [sqrt(1/2), sqrt(2))
+  e -= c;
+  const double u = __builtin_fma(m, 256.0, 0x1.8p52);  // the low word of 1.5*2^52 + n is n
+  int i = __double2loint(u) - CHS_LOGTAB_I0;
+  i = min(max(i, 0), CHS_LOGTAB_N - 1);                 // (x <= 0 or NaN: any entry; the caller flags the domain)
+  const double2 t = tab[i];
+  const double r = __builtin_fma(m, t.x, -1.0);
+  double p = __builtin_fma(r, 1.0 / 7.0, -1.0 / 6.0);
+  p = __builtin_fma(r, p, 1.0 / 5.0);
+  p = __builtin_fma(r, p, -1.0 / 4.0);
+  p = __builtin_fma(r, p, 1.0 / 3.0);
+  p = __builtin_fma(r, p, -0.5);
+  const double lp = __builtin_fma(r * r, p, r);
+  const double k = (double)e;
+  return __builtin_fma(k, CHS_LN2_HI, t.y) + __builtin_fma(k, CHS_LN2_LO, lp);
+}
+
 template <typename T> __device__ __forceinline__ T chs_log_pos(T x);
 template <> __device__ __forceinline__ double chs_log_pos<double>(double x) { return chs_log_pos_f64(x); }
 template <> __device__ __forceinline__ float chs_log_pos<float>(float x) { return logf(x); }
+template <typename T> __device__ __forceinline__ T chs_log_pos_tab(T x, const double2* tab);
+template <> __device__ __forceinline__ double chs_log_pos_tab<double>(double x, const double2* tab) { return chs_log_pos_tab_f64(x, tab); }
+template <> __device__ __forceinline__ float chs_log_pos_tab<float>(float x, const double2*) { return logf(x); }
 
 template <typename T> __device__ __forceinline__ T chs_log(T x);
 template <> __device__ __forceinline__ double chs_log<double>(double x) { return chs_log_f64(x); }

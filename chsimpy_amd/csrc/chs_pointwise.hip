@@ -498,10 +498,14 @@ int chs_launch_jitter(Engine* E) {
 // ---------------------------------------------------------------------------
 __global__ void k_test_math(int which, const double* __restrict__ a, const double* __restrict__ b,
                             double* __restrict__ out, long long n) {
+  __shared__ double2 ltab[CHS_LOGTAB_N];
+  for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += blockDim.x) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
+  __syncthreads();
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double r;
-  if (which == 0) r = chs_log_f64(a[i]);
+  if (which == 5) r = chs_log_pos_tab_f64(a[i], ltab);
+  else if (which == 0) r = chs_log_f64(a[i]);
   else if (which == 1) r = chs_log_ratio_f64(a[i], b[i]);
   else if (which == 4) r = chs_log_pos_f64(a[i]);
   else if (which == 2) r = chs_mu<double>(a[i], b[0], b[1], b[2], b[3]);
@@ -510,7 +514,7 @@ __global__ void k_test_math(int which, const double* __restrict__ a, const doubl
 }
 
 extern "C" int chs_test_math(int device, int which, const double* a, const double* b, double* out, int64_t n) {
-  if (!a || !out || n <= 0 || which < 0 || which > 4) { chs_set_error("chs_test_math: bad argument"); return CHS_EINVAL; }
+  if (!a || !out || n <= 0 || which < 0 || which > 5) { chs_set_error("chs_test_math: bad argument"); return CHS_EINVAL; }
   CHS_HIP(hipSetDevice(device));
   double *da = nullptr, *db = nullptr, *dout = nullptr;
   const size_t nb_b = (which == 1) ? (size_t)n : 4;

@@ -150,7 +150,8 @@ int chs_get_mu(chs_handle h, double* host_mu);
 /* Device math primitives evaluated elementwise on `device` (accuracy tests):
  * which = 0: log(a)   1: log(a/b)   2: EnergieEut(a) with (RT,BRT,A0,A1) = b[0..3]
  *         3: bulk energy density(a) with (RT,B,A0,A1) = b[0..3]  (solver.py:218-221)
- *         4: log(a) for a > 0 (the variant the fused row kernel uses) */
+ *         4: log(a) for a > 0 (division-based variant)
+ *         5: log(a) for a > 0, table-driven (the variant the fused row kernel uses) */
 int chs_test_math(int device, int which, const double* a, const double* b, double* out, int64_t n);
 /* Which engine the handle resolved to (CHS_ENGINE_DIRECT / CHS_ENGINE_FAST). */
 int chs_engine(chs_handle h);

@@ -39,6 +39,22 @@ def test_log_pos_accuracy(gpu):
     assert ulp_err(got[ok], ref[ok]).max() <= 2.5
 
 
+def test_log_pos_table_accuracy(gpu):
+    """The table-driven log (no division) of the fused row kernel's pointwise part."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.random(300000), 1 - rng.random(100000) * 1e-3, 1 - rng.random(50000) * 1e-9,
+                        np.exp(rng.uniform(-700, 700, 100000)), np.linspace(0.70, 0.72, 50001),
+                        np.linspace(0.99, 1.01, 200001), np.arange(181, 363) / 256.0,
+                        (np.arange(181, 363) + 0.5) / 256.0, np.nextafter((np.arange(181, 363) + 0.5) / 256.0, 0)])
+    x = x[x > 0]
+    got = _lib.test_math(5, x)
+    ref = np.log(np.asarray(x, dtype=np.longdouble)).astype(np.float64)
+    ok = ref != 0
+    e = ulp_err(got[ok], ref[ok])
+    assert e.max() <= 2.5, (e.max(), x[ok][np.argmax(e)])
+    assert np.all(got[x == 1.0] == 0.0)
+
+
 def test_log_ratio_accuracy(gpu):
     rng = np.random.default_rng(1)
     U = np.concatenate([rng.uniform(0.5, 1 - 1e-9, 300000), rng.uniform(1e-9, 0.5, 300000),
