@@ -146,6 +146,9 @@ __device__ __forceinline__ void stagger_start() {
 #ifndef CHS_LOG_TABLE
 #define CHS_LOG_TABLE 1  // table-driven log in the fused row kernel's pointwise part (0: division-based)
 #endif
+#ifndef CHS_COL_H0
+#define CHS_COL_H0 0  // 1: hat_U of slot 0 requested before the forward passes (measured neutral)
+#endif
 // ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
 #ifndef CHS_COL_PARK
 #define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
@@ -532,8 +535,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // constants of the spectral stage, requested here: their latency disappears behind the stage-in
   // (loaded where they are used they cost every workgroup ~4 K cycles of waiting)
   const double lam1 = st->lam1, lam2 = st->lam2;
-  const double lc = lam[kc];
-  const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc + 1] : 0.0;
+  // (the column index is wave-uniform when a group fills whole wavefronts: scalar loads, no VGPRs)
+  const int kc_u = (C::G >= 64) ? __builtin_amdgcn_readfirstlane(kc) : kc;
+  const double lc = lam[kc_u];
+  const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc_u + 1] : 0.0;
   // What the spectral stage reads per recombination slot (4 positions of this lane): {lambda_kr,
   // sin^2(pi kr/N)} from the table (L2), fetched one slot ahead, and hat_U.  The lane's 2E values of
   // hat_U are parked in LDS long before they are needed (every lane reads back only what it wrote,
@@ -542,14 +547,23 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   //   positions E..2E-1  requested after the forward passes      -> hpark2 = the exchange scratch,
   //                      idle until the inverse passes
   struct Fetched { double2 ls[4]; T h[(CHS_COL_PARK != 0) ? 1 : 4]; };
+  // hat_U of positions 0..3 -- the first slot of every lane and the special lane's own slot --
+  // requested before the forward passes (CHS_COL_H0): nothing waits for it at the start of the stage
+  constexpr bool H0 = (MODE == MODE_STEP) && (CHS_COL_H0 != 0) && (CHS_COL_PARK == 0);
+  T h0[4] = {T(0), T(0), T(0), T(0)};
   auto fetch = [&](int pbase, const int idx[4]) {
     Fetched p;
 #pragma unroll
     for (int t = 0; t < 4; ++t) p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];
     if constexpr (CHS_COL_PARK == 0) {
-      const T* hl = hcol + fc_opaque(l);
+      if (H0 && pbase == 0) {  // (compile-time after inlining)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) p.h[t] = hl[(size_t)(pbase + t) * C::G];
+        for (int t = 0; t < 4; ++t) p.h[t] = h0[t];
+      } else {
+        const T* hl = hcol + fc_opaque(l);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) p.h[t] = hl[(size_t)(pbase + t) * C::G];
+      }
     }
     return p;
   };
@@ -621,6 +635,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     if constexpr (PARK) {
 #pragma unroll
       for (int p = 0; p < C::E; ++p) hpark1[p * C::THREADS] = hearly[p];
+    }
+    if constexpr (H0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h0[t] = hcol[(size_t)t * C::G + l];
     }
     fwd_passes<C>(re, im, scr, tb, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 2);
