@@ -266,6 +266,39 @@ def test_properties_at_full_size(gpu):
     s.close()
 
 
+def test_config2_n4096_5000steps_invariants(gpu):
+    """BASELINE.json configs[2] itself (N=4096, ntmax=5000, fp64), one solve_or_resume call on the fused
+    pipeline (deferred bookkeeping, U kept in registers between steps): invariants of the scheme that do
+    not need the oracle at this size -- mass conservation, energy decay (the scheme is energy stable at
+    this step size), E2 growing from its start value, a complete record, and the same run cut into
+    calls of 1000 steps (hat_U re-derived per call as in solver.py:159) agreeing to round-off."""
+    N, nt = 4096, 5000
+    p = make(N, nt, 'fast')
+    s = chsimpy_amd.Solver(p)
+    s.prepare()
+    m0 = s.U_init.mean()
+    sol = s.solve_or_resume()
+    td = sol.timedata.data()
+    assert td.shape == (nt, 9) and not np.any(np.isnan(td))
+    assert np.array_equal(td[:, 0], np.arange(nt))
+    assert sol.U.mean() == pytest.approx(m0, rel=1e-12)
+    E = td[:, 1]
+    assert np.all(np.diff(E) <= 1e-12 * np.abs(E[:-1]))        # total energy never grows
+    assert td[-1, 2] > td[0, 2]                                  # the gradient energy has started to grow
+    assert 0.0 < sol.U.min() and sol.U.max() < 1.0
+    U1, td1 = sol.U.copy(), td.copy()
+    s.close()
+    s = chsimpy_amd.Solver(p)
+    s.prepare()
+    for _ in range(5):
+        sol = s.solve_or_resume(1000)
+    td2 = sol.timedata.data()
+    assert td2.shape == td1.shape
+    assert np.allclose(td2[:, 1:3], td1[:, 1:3], rtol=1e-9, atol=0)
+    assert np.allclose(sol.U, U1, rtol=1e-9, atol=0), relerr(sol.U, U1)
+    s.close()
+
+
 def test_simulator_export_csv(gpu, tmp_path):
     p = make(64, 10)
     p.export_csv = 'U,E,E2,SA'
