@@ -32,8 +32,10 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    # defaults: the GPU needs ~70 ms of sustained work before step times settle (a 200-step call
+    # right behind a 20-step warmup measures ~5 % slower than the following ones)
+    ap.add_argument('--steps', type=int, default=1000)
+    ap.add_argument('--warmup', type=int, default=300)
     ap.add_argument('--grid', type=int, default=4096, help='N (default: BASELINE.json configs[2])')
     ap.add_argument('--dtype', default='float64')
     ap.add_argument('--engine', default='auto')
@@ -133,9 +135,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warmup (untimed).  The first call after prepare() runs nsteps-1 iterations
-    # (solver.py:160-165), so ask for one more.
-    s.solve_or_resume(a.warmup + 1)
+    # warmup (untimed): W steps through the same C-ABI call as the timed region, so that nothing
+    # (the 128 MB download of U at the end of Solver.solve_or_resume, tens of ms of an idle GPU)
+    # sits between the warmup and the timed steps and lets the clocks drop.
+    rows_w, rc_w = eng.step_n(a.warmup)
+    assert rc_w == 0 and rows_w.shape[0] == a.warmup
     # keep the input resident: nothing is uploaded inside the timed region; the
     # entry transform hat_U = dctn(U) of solve_or_resume (solver.py:159) is part of it.
     sync()

@@ -61,6 +61,7 @@ static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 static int ensure_rows(Engine* E, long long n) {
   if (n < 1) n = 1;
   if (n <= E->rowsCap) return CHS_OK;
+  if (n < 65536) n = 65536;  // (4.7 MB) no reallocation -- a device-wide sync -- inside ordinary calls
   if (E->dRows) hipFree(E->dRows);
   E->dRows = nullptr;
   CHS_HIP(hipMalloc(&E->dRows, sizeof(double) * 9 * (size_t)n));
