@@ -3,7 +3,7 @@
 #   tools/ab.sh [rounds] [bench args...]  -- runs bench.py with every chsimpy_amd/lib/variants/*.so, interleaved
 rounds=${1:-2}
 shift
-args=${@:---steps 300 --warmup 30}
+args=${@:---steps 300 --warmup 300}
 mkdir -p gpurun_out
 : > gpurun_out/ab.log
 for r in $(seq $rounds); do
