@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     # defaults: the GPU needs ~70 ms of sustained work before step times settle (a 200-step call
     # right behind a 20-step warmup measures ~5 % slower than the following ones)
-    ap.add_argument('--steps', type=int, default=1000)
+    ap.add_argument('--steps', type=int, default=5000, help='timed steps (default: ntmax of BASELINE.json configs[2])')
     ap.add_argument('--warmup', type=int, default=300)
     ap.add_argument('--grid', type=int, default=4096, help='N (default: BASELINE.json configs[2])')
     ap.add_argument('--dtype', default='float64')
