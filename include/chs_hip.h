@@ -92,7 +92,9 @@ typedef struct chs_handle_s* chs_handle;
 /* Create an engine for one simulation.  `lambda` is the host-computed 1-D table
  * lam_i = 2cos(pi i/(N-1)) - 2, i = 0..N-1 (chsimpy/utils.py:34-36); the N x N
  * grids CHeig/Seig of utils.py:39-49 are never materialised, they are formed on
- * the fly from this table and the current delt. */
+ * the fly from this table and the current delt.
+ * Environment (read here, test hook): CHS_ADAPT_SWEEP=1 keeps the separate sweep
+ * of U for the adaptive-step column sums instead of the fused row kernel's. */
 int chs_create(const chs_consts* consts, const double* lambda, chs_handle* out);
 int chs_destroy(chs_handle h);
 
