@@ -120,7 +120,7 @@ def run_experiment_gpu(run_id, init_params, rand_values, A_list, U_init=None, po
         except Exception:  # sympy missing or no two roots: keep NaN, the run itself is valid
             pass
     itargmax = int(np.argmax(solution.E2))
-    simulator.solver.close()
+    simulator.solver.close(fetch_U=False)   # the record needs scalars only
     return (solution.A0, solution.A1, ca, cb, sa, sb, solution.tau0, solution.t0, itargmax, run_id,
             np.nan if fac_A0 is None else fac_A0, np.nan if fac_A1 is None else fac_A1)
 

@@ -10,7 +10,8 @@ _TIMEDATA_NAMES = ('E', 'E2', 'SA', 'domtime', 'Ra', 'L2', 'PS', 'delt', 'it_ran
 class Solution:
     def __init__(self, params=None):
         p = self.params = params
-        self.U = None
+        self._U = None          # the field (solution.py:21); see the property U below
+        self._U_fetch = None    # pending download of the device field
         self.timedata = None
         # molar area [um^2/mol], solution.py:25
         self.Am = (25.13 * 1e6 / p.N_A) ** (2 / 3) * p.N_A
@@ -40,6 +41,25 @@ class Solution:
         self.t0 = 0
         self.computed_steps = 0
         self.stop_reason = 'None'
+
+    # solution.py:21 `self.U`.  The device loop leaves the field in HBM; it is downloaded (N*N*8 bytes
+    # over PCIe) when somebody looks at it, not after every solve_or_resume chunk.
+    @property
+    def U(self):
+        fetch = self.__dict__.get('_U_fetch')
+        if fetch is not None:
+            self.__dict__['_U_fetch'] = None
+            self.__dict__['_U'] = fetch()
+        return self.__dict__.get('_U')
+
+    @U.setter
+    def U(self, value):
+        self.__dict__['_U_fetch'] = None
+        self.__dict__['_U'] = value
+
+    def __getstate__(self):
+        _ = self.U  # materialise a pending download: the engine does not travel
+        return self.__dict__
 
     # The N x N grids of solution.py:52-55, on demand (host convenience only).
     @property

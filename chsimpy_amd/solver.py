@@ -100,8 +100,14 @@ class Solver:
         sol.stop_reason = _lib.STOP_NAMES[st.stop_reason]
         return st
 
-    def close(self):
+    def close(self, fetch_U=True):
+        """Free the device engine.  A download of the field that is still pending (Solution.U is
+        fetched on first access) happens now unless the caller does not need it."""
         if self._engine is not None:
+            if fetch_U:
+                _ = self.solution.U
+            else:
+                self.solution.U = self.solution.__dict__.get('_U')
             self._engine.close()
             self._engine = None
 
@@ -153,7 +159,8 @@ class Solver:
                     break
             if count == 0:
                 self._pull_state()
-        self.solution.U = eng.get_U()
+        self.solution.U = None
+        self.solution._U_fetch = eng.get_U   # downloaded when somebody looks at solution.U
         return self.solution
 
     def _absorb(self, rows, rc, requested):

@@ -149,6 +149,28 @@ def test_resume_chunks_match_oracle_chunks(gpu):
     s.close()
 
 
+def test_solution_U_is_downloaded_on_demand(gpu):
+    """Solution.U (solution.py:21) is fetched from the device when it is looked at, not after every
+    chunk: chunked driving (simulator.py:62-81) then costs no N*N*8-byte PCIe transfer per chunk."""
+    p = make(128, 0)
+    s = chsimpy_amd.Solver(p)
+    o = orc.OracleSolver(orc.make_params(128, 0))
+    s.prepare(); o.prepare()
+    sol = s.solve_or_resume(6); o.solve_or_resume(6)
+    assert sol.__dict__['_U_fetch'] is not None and sol.__dict__['_U'] is None     # nothing downloaded yet
+    sol = s.solve_or_resume(9); o.solve_or_resume(9)
+    assert sol.__dict__['_U_fetch'] is not None
+    U = sol.U                                                                        # now
+    assert sol.__dict__['_U_fetch'] is None and U is sol.U
+    assert np.allclose(U, o.U, rtol=RTOL, atol=0)
+    sol = s.solve_or_resume(3); o.solve_or_resume(3)
+    s.close()                                                                        # a pending download happens at close
+    assert np.allclose(sol.U, o.U, rtol=RTOL, atol=0)
+    s2 = chsimpy_amd.Solver(p); s2.prepare(); sol2 = s2.solve_or_resume(4)
+    s2.close(fetch_U=False)
+    assert sol2.U is None and 'U' not in sol2.scalars()
+
+
 def test_energy_stop_without_full_sim(gpu):
     """full_sim=False: stop at the first step with E2[it-1] > E2[it] > E2[0]; the
     returned U is the one of the stopping step (solver.py:242-251).  delt=3e-6 reaches
