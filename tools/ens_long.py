@@ -1,0 +1,12 @@
+import sys, time, os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import chsimpy_amd
+from chsimpy_amd import experiment as ex
+for conc in (1, 2, 3, 4):
+    p = chsimpy_amd.Parameters()
+    p.N, p.ntmax, p.full_sim, p.kappa_tilde, p.file_id = 2048, 4000, True, 0.0002989112919661156, '/tmp/ens'
+    ep = ex.ExperimentParams(); ep.runs = 4
+    t0 = time.time()
+    recs = ex.run_ensemble(p, ep, run_fn=lambda i, pp, rv, al: ex.run_experiment_gpu(i, pp, rv, al, None, postprocess=False), concurrent=conc)
+    dt = time.time() - t0
+    print(f"concurrent={conc}: 4 runs x 3999 steps at N=2048 in {dt:.2f} s -> {4*3999/dt:.0f} timesteps/s aggregate")
