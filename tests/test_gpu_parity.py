@@ -128,6 +128,15 @@ def test_config1_n512_1000steps(gpu):
     compare_run(make(512, 1000, 'auto'), {})
 
 
+@pytest.mark.parametrize("N,nt", [(1024, 100), (2048, 40), (4096, 12)])
+def test_large_grids_against_the_oracle(gpu, N, nt):
+    """The larger fast-engine configurations step by step against the oracle itself, as far as the
+    oracle's CPU time allows (about 0.1 us per grid point and step): every configuration has its own
+    workgroup shapes and radices, N=4096 is the headline size."""
+    p = make(N, nt, 'fast')
+    compare_run(p, {})
+
+
 def test_resume_chunks_match_oracle_chunks(gpu):
     """solve_or_resume in chunks (simulator.py:62-81): nsteps-1 on the first call,
     hat_U re-derived per call."""
