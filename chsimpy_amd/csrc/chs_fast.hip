@@ -149,6 +149,9 @@ __device__ __forceinline__ void stagger_start() {
 #ifndef CHS_COL_H0
 #define CHS_COL_H0 0  // 1: hat_U of slot 0 requested before the forward passes (measured neutral)
 #endif
+#ifndef CHS_COL_TW_LDS
+#define CHS_COL_TW_LDS 1  // k_col<MODE_STEP>: radix-pass twiddles from LDS
+#endif
 // ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
 #ifndef CHS_COL_PARK
 #define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
@@ -482,6 +485,12 @@ struct ColStage {
   }
 };
 
+// elements of the pass twiddle tables tw0 | twa | twb (contiguous in the table buffer, build_tables)
+template <class C>
+constexpr int col_tw_elems() {
+  return 2 * ((C::R0 - 1) * C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
+}
+
 template <class C>
 constexpr int col_lds_elems() {
   return (C::C * C::SCR > ColStage<C>::ELEMS) ? C::C * C::SCR : ColStage<C>::ELEMS;
@@ -531,6 +540,21 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   const int kc = ct * C::CT + hh * C::C + sub;  // this group's column
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
+  // MODE_STEP: the twiddles of the radix passes come from LDS (copied once per workgroup; visible
+  // behind the barriers of the stage-in): no L2 round trip per pass, and no load that would have to
+  // wait behind the hat_U stores at the start of the inverse passes
+  FTables<T> tbp = tb;
+  if constexpr (MODE == MODE_STEP && CHS_COL_TW_LDS) {
+    T* ltw = lds + col_lds_elems<C>() + (CHS_COL_PARK ? C::E * C::THREADS : 0);
+    constexpr int NTW = col_tw_elems<C>();
+    for (int i = 2 * threadIdx.x; i < NTW; i += 2 * C::THREADS) {
+      if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(ltw + i) = *reinterpret_cast<const double2*>(tb.tw0 + i);
+      else *reinterpret_cast<float2*>(ltw + i) = *reinterpret_cast<const float2*>(tb.tw0 + i);
+    }
+    tbp.tw0 = ltw;
+    tbp.twa = ltw + 2 * (C::R0 - 1) * C::L1;
+    tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
+  }
   T* hcol = hat + (size_t)kc * C::N;
   // constants of the spectral stage, requested here: their latency disappears behind the stage-in
   // (loaded where they are used they cost every workgroup ~4 K cycles of waiting)
@@ -640,7 +664,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
 #pragma unroll
       for (int t = 0; t < 4; ++t) h0[t] = hcol[(size_t)t * C::G + l];
     }
-    fwd_passes<C>(re, im, scr, tb, l);
+    fwd_passes<C>(re, im, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 2);
     if constexpr (PARK) {
       __syncthreads();  // every wavefront has read its last exchange: the scratch is free
@@ -712,7 +736,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     // wave-local groups exchange behind wavefront fences only: the parked hat_U of another
     // wavefront may lie in this group's scratch, so everybody must be through the spectral stage
     if constexpr (PARK && C::WAVE_LOCAL) __syncthreads();
-    inv_passes<C>(re, im, scr, tb, l);
+    inv_passes<C>(re, im, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 4);
     // ---- stage out: quads -> tile rows
     T* tile = Tout + (size_t)ct * C::N * C::CT;
@@ -793,7 +817,8 @@ struct Launch {
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
   static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && C::R0 == 8;
   // + the parking area of half a hat_U column per lane (k_col<MODE_STEP>)
-  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (CHS_COL_PARK ? (size_t)CC::E * CC::THREADS : 0)) * sizeof(T) + CHS_COL_LDS_PAD;
+  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (CHS_COL_PARK ? (size_t)CC::E * CC::THREADS : 0) +
+                                     (CHS_COL_TW_LDS ? (size_t)col_tw_elems<CC>() : 0)) * sizeof(T) + CHS_COL_LDS_PAD;
   static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
 
   template <class K>
