@@ -35,7 +35,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     # defaults: the GPU needs ~70 ms of sustained work before step times settle (a 200-step call
     # right behind a 20-step warmup measures ~5 % slower than the following ones)
-    ap.add_argument('--steps', type=int, default=5000, help='timed steps (default: ntmax of BASELINE.json configs[2])')
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 5000 = ntmax of BASELINE.json configs[2]; '
+                    '1000 with --energy-stop, whose run ends at the E2 maximum)')
     ap.add_argument('--warmup', type=int, default=300)
     ap.add_argument('--grid', type=int, default=4096, help='N (default: BASELINE.json configs[2])')
     ap.add_argument('--dtype', default='float64')
@@ -44,7 +45,10 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=0, help='0 = size the CPU sample automatically')
     ap.add_argument('--profile-steps', type=int, default=20)
     ap.add_argument('--energy-stop', action='store_true', help='full_sim=False (the reference default: stop at the E2 maximum); not the headline workload')
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 1000 if a.energy_stop else 5000
+    return a
 
 
 def make_params(N, dtype, engine, device, rank, full_sim=True):
