@@ -152,6 +152,9 @@ __device__ __forceinline__ void stagger_start() {
 #ifndef CHS_COL_TW_LDS
 #define CHS_COL_TW_LDS 1  // k_col<MODE_STEP>: radix-pass twiddles from LDS
 #endif
+#ifndef CHS_ROW_LDS_PAD
+#define CHS_ROW_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower the row kernels' occupancy
+#endif
 // ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
 #ifndef CHS_COL_PARK
 #define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
@@ -813,7 +816,7 @@ static FTables<T> get_tables(Engine* E) {
 template <class C, class CC = C>
 struct Launch {
   using T = typename C::T;
-  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0);
+  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0) + CHS_ROW_LDS_PAD;
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
   static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && C::R0 == 8;
   // + the parking area of half a hat_U column per lane (k_col<MODE_STEP>)
