@@ -259,7 +259,7 @@ static int enter(Engine* E) {
 // one iteration of solver.py:165-249
 static int one_step(Engine* E, bool first, bool last) {
   int rc;
-  const bool jitter = E->dNoise && E->jitter > 0.0 && E->jitter < 0.1;
+  const bool jitter = (E->dNoise || E->jitterPcg) && E->jitter > 0.0 && E->jitter < 0.1;
   if (E->engine == CHS_ENGINE_FAST && !jitter) {
     // fused pipeline: k_col, k_row_inv (+ record partials + next step's row pass), k_step_tail
     return chs_fast_step(E, first, last);
@@ -280,7 +280,7 @@ static int one_step(Engine* E, bool first, bool last) {
     if ((rc = chs_fast_step_unfused(E))) return rc;
   }
   if (jitter) {                                    // 210-211
-    if ((rc = chs_launch_jitter(E))) return rc;
+    if ((rc = E->jitterPcg ? chs_launch_jitter_pcg(E) : chs_launch_jitter(E))) return rc;
     if ((rc = chs_launch_sum(E, 0))) return rc;
   }
   if ((rc = chs_launch_diag(E, 0))) return rc;     // 213-228
@@ -313,7 +313,7 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   }
   E->hat_valid = true;
   E->timer.on = profile;
-  const bool fused = (E->engine == CHS_ENGINE_FAST) && !(E->dNoise && E->jitter > 0.0 && E->jitter < 0.1);
+  const bool fused = (E->engine == CHS_ENGINE_FAST) && !((E->dNoise || E->jitterPcg) && E->jitter > 0.0 && E->jitter < 0.1);
   if (fused && nsteps > 0) {
     if ((rc = chs_fast_prologue(E))) { E->timer.on = false; return rc; }
   }
@@ -385,11 +385,24 @@ extern "C" const char* chs_kernel_name(chs_handle h, int slot) {
   return E->engine == CHS_ENGINE_DIRECT ? direct[slot] : fast[slot];
 }
 
+extern "C" int chs_set_jitter_pcg64(chs_handle h, double jitter, const uint64_t state[2], const uint64_t inc[2]) {
+  Engine* E = (Engine*)h;
+  if (!E || !state || !inc) { chs_set_error("chs_set_jitter_pcg64: null argument"); return CHS_EINVAL; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  if (E->dNoise) { hipFree(E->dNoise); E->dNoise = nullptr; }
+  E->jitter = jitter;
+  E->jitterPcg = true;
+  E->pcgState[0] = state[0]; E->pcgState[1] = state[1];
+  E->pcgInc[0] = inc[0]; E->pcgInc[1] = inc[1];
+  return CHS_OK;
+}
+
 extern "C" int chs_set_jitter_noise(chs_handle h, double jitter, const double* host_noise) {
   Engine* E = (Engine*)h;
   if (!E) { chs_set_error("chs_set_jitter_noise: null handle"); return CHS_EINVAL; }
   CHS_HIP(hipSetDevice(E->hc.device));
   E->jitter = jitter;
+  E->jitterPcg = false;
   if (!host_noise) {  // switch jitter off
     if (E->dNoise) { hipFree(E->dNoise); E->dNoise = nullptr; }
     return CHS_OK;

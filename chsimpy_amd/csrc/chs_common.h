@@ -174,6 +174,9 @@ struct Engine {
   int parity = 0;
   bool tailDeferred = false;  // the tail of the previous step is still to run
   unsigned stepCount = 0;     // k_col<MODE_STEP> launches so far (tile walk direction alternates)
+  // jitter noise generated on the device: numpy's PCG64 stream continued from the host generator's state
+  bool jitterPcg = false;
+  unsigned long long pcgState[2] = {0, 0}, pcgInc[2] = {0, 0};  // {hi, lo}
   bool fusedAdapt = false;    // the fused row kernel adds up the adaptive-step integrand itself
   double* dPartColRows = nullptr;  // [nRowBlocks][N] partial column sums of that integrand
   bool storeU = true;         // the fused row kernel writes U on intermediate steps (chs_fast_step)
@@ -222,6 +225,7 @@ int chs_launch_sum(Engine* E, int ignore_halt);  // meanU <- mean(dU)
 int chs_launch_diag(Engine* E, int ignore_halt);  // dU -> diag partials
 int chs_launch_fin(Engine* E, int prepare_mode, int fused = 0);
 int chs_launch_jitter(Engine* E);
+int chs_launch_jitter_pcg(Engine* E);  // U += jitter*(2*r-1), r from the PCG64 stream; advances E->pcgState by N*N
 int chs_pointwise_alloc(Engine* E);
 void chs_pointwise_free(Engine* E);
 

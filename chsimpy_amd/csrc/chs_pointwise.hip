@@ -325,6 +325,80 @@ __global__ __launch_bounds__(PW_THREADS) void k_jitter(T* __restrict__ U, const 
 }
 
 // ---------------------------------------------------------------------------
+// k_jitter_pcg: the same with r drawn on the device from numpy's PCG64 stream (XSL-RR 128/64:
+// state <- state*MULT + inc, output = rotr64(hi ^ lo, hi >> 58), double = (out >> 11) * 2^-53;
+// element i of the C-ordered array takes draw i).  Thread t handles elements t, t+TT, t+2TT, ...
+// (coalesced): it jumps to draw t once (LCG jump-ahead, O(log t)) and then strides TT draws at a time
+// with the precomputed jump (multTT, plusTT).
+// ---------------------------------------------------------------------------
+typedef unsigned __int128 chs_u128;
+#define CHS_PCG_MULT ((((chs_u128)0x2360ED051FC65DA4ULL) << 64) | (chs_u128)0x4385DF649FCCF645ULL)
+__host__ __device__ inline void chs_pcg_jump(chs_u128 delta, chs_u128 inc, chs_u128& acc_mult, chs_u128& acc_plus) {
+  chs_u128 cur_mult = CHS_PCG_MULT, cur_plus = inc;
+  acc_mult = 1; acc_plus = 0;
+  while (delta > 0) {
+    if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+    delta >>= 1;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void k_jitter_pcg(T* __restrict__ U, double jitter, size_t total,
+                                                           unsigned long long s_hi, unsigned long long s_lo,
+                                                           unsigned long long i_hi, unsigned long long i_lo,
+                                                           unsigned long long m_hi, unsigned long long m_lo,
+                                                           unsigned long long p_hi, unsigned long long p_lo,
+                                                           const DevState* __restrict__ st) {
+  if (st->halt) return;
+  const size_t tt = (size_t)gridDim.x * PW_THREADS, t = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  const chs_u128 inc = ((chs_u128)i_hi << 64) | i_lo;
+  const chs_u128 multTT = ((chs_u128)m_hi << 64) | m_lo, plusTT = ((chs_u128)p_hi << 64) | p_lo;
+  chs_u128 am, ap;
+  chs_pcg_jump((chs_u128)t + 1, inc, am, ap);  // the state behind draw t (a draw steps first, then outputs)
+  chs_u128 s = (((chs_u128)s_hi << 64) | s_lo) * am + ap;
+  for (size_t i = t; i < total; i += tt) {
+    const unsigned long long hi = (unsigned long long)(s >> 64), lo = (unsigned long long)s;
+    const unsigned long long x = hi ^ lo;
+    const unsigned rot = (unsigned)(hi >> 58);
+    const unsigned long long o = (x >> rot) | (x << ((64u - rot) & 63u));
+    const double r = (double)(o >> 11) * (1.0 / 9007199254740992.0);
+    {
+#pragma clang fp contract(off)
+      U[i] = (T)((double)U[i] + jitter * (2.0 * r - 1.0));
+    }
+    s = s * multTT + plusTT;
+  }
+}
+
+int chs_launch_jitter_pcg(Engine* E) {
+  const size_t total = (size_t)E->N * E->N;
+  int blocks = (int)((total + PW_THREADS * 64 - 1) / ((size_t)PW_THREADS * 64));  // 64 draws per thread
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  const chs_u128 state = ((chs_u128)E->pcgState[0] << 64) | E->pcgState[1];
+  const chs_u128 inc = ((chs_u128)E->pcgInc[0] << 64) | E->pcgInc[1];
+  chs_u128 mtt, ptt, mall, pall;
+  chs_pcg_jump((chs_u128)blocks * PW_THREADS, inc, mtt, ptt);
+  chs_slot_begin(E, SLOT_MISC);
+  DISPATCH_T(E,
+    (k_jitter_pcg<double><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, E->jitter, total, E->pcgState[0], E->pcgState[1],
+        E->pcgInc[0], E->pcgInc[1], (unsigned long long)(mtt >> 64), (unsigned long long)mtt,
+        (unsigned long long)(ptt >> 64), (unsigned long long)ptt, E->dState)),
+    (k_jitter_pcg<float><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, E->jitter, total, E->pcgState[0], E->pcgState[1],
+        E->pcgInc[0], E->pcgInc[1], (unsigned long long)(mtt >> 64), (unsigned long long)mtt,
+        (unsigned long long)(ptt >> 64), (unsigned long long)ptt, E->dState)));
+  chs_slot_end(E, SLOT_MISC);
+  CHS_HIP(hipGetLastError());
+  // the generator moves on by one field per step, whether or not a stop has turned the kernel into a
+  // no-op: the caller re-seeds from its own generator at the next call
+  chs_pcg_jump((chs_u128)total, inc, mall, pall);
+  const chs_u128 next = state * mall + pall;
+  E->pcgState[0] = (unsigned long long)(next >> 64); E->pcgState[1] = (unsigned long long)next;
+  return CHS_OK;
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 int chs_pointwise_alloc(Engine* E) {

@@ -28,6 +28,8 @@ class Solver:
         self._engine = None
 
         self.create_rand = None
+        self._pcg = None
+        self.device_rng = True   # draw the jitter noise on the device when the generator is numpy's PCG64
         self.U_init = None
         # initial concentration field, solver.py:59-82
         if U_init is not None:
@@ -52,6 +54,7 @@ class Solver:
         else:
             rng = np.random.Generator(np.random.PCG64(params.seed))
             self.create_rand = lambda n: rng.random((n, n))
+            self._pcg = rng   # the device can continue this stream itself (jitter, solve_or_resume)
         if self.U_init is None:
             self.U_init = params.XXX + (params.XXX * 0.01 * (self.create_rand(N) - 0.5))
 
@@ -146,8 +149,20 @@ class Solver:
             eng.set_jitter_noise(0.0, None)
             rows, rc = eng.step_n(count)
             self._absorb(rows, rc, count)
+        elif self._pcg is not None and self.device_rng:
+            # The reference's default generator (numpy PCG64, solver.py:78-82): the device continues
+            # its stream from the generator's current state -- N*N draws per step in C order, exactly
+            # what `create_rand(N)` would have returned (solver.py:211) -- and the whole chunk runs as
+            # one device loop; afterwards the host generator is moved on by what the device consumed.
+            st = self._pcg.bit_generator.state['state']
+            eng.set_jitter_pcg64(p.jitter, st['state'], st['inc'])
+            rows, rc = eng.step_n(count)
+            try:
+                self._absorb(rows, rc, count)
+            finally:
+                self._pcg.bit_generator.advance(int(rows.shape[0]) * p.N * p.N)
         else:
-            # The noise comes from the host generator so that its stream stays the
+            # Other generators: the noise comes from the host generator so that its stream stays the
             # reference's (solver.py:211); hat_U is carried between the one-step
             # calls exactly as inside the reference's loop.
             first = True

@@ -141,6 +141,12 @@ int chs_set_state(chs_handle h, const chs_state* in);
  * host keeps its stream bit-identical.  hat_U is left untouched, as in the
  * reference. */
 int chs_set_jitter_noise(chs_handle h, double jitter, const double* host_noise);
+/* The same with the noise drawn on the device: the stream of numpy's PCG64 (`Generator.random`,
+ * the reference's default generator, solver.py:78-82,211) continued from the 128-bit `state` and
+ * `inc` of the host generator ({high word, low word}); every step consumes N*N draws in C order.
+ * The caller advances its own generator by N*N per completed step afterwards
+ * (`bit_generator.advance`).  jitter outside (0, 0.1) or a later chs_set_jitter_noise switches it off. */
+int chs_set_jitter_pcg64(chs_handle h, double jitter, const uint64_t state[2], const uint64_t inc[2]);
 
 /* Test / diagnostic hooks (not on the reference seam). */
 /* 2-D orthonormal DCT-II (inverse=0) or DCT-III (inverse=1) of a host array

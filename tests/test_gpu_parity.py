@@ -248,9 +248,34 @@ def test_adaptive_time(gpu):
     s.close()
 
 
-def test_jitter_host_noise_stream(gpu):
-    p = make(64, 12, 'auto', jitter=0.001)
+@pytest.mark.parametrize("N,engine", [(64, 'auto'), (128, 'fast')])
+def test_jitter_host_noise_stream(gpu, N, engine):
+    """solver.py:210-211: U += jitter*(2*rand - 1) between the inverse transform and the record, the
+    noise from the run's own generator (drawn on the device for numpy's PCG64, see below)."""
+    p = make(N, 12, engine, jitter=0.001)
     compare_run(p, dict(jitter=0.001))
+
+
+@pytest.mark.parametrize("N,engine", [(64, 'direct'), (256, 'fast')])
+def test_jitter_noise_drawn_on_the_device_continues_the_host_stream(gpu, N, engine):
+    """With the reference's default generator (numpy PCG64) the device draws the jitter noise itself
+    (chs_set_jitter_pcg64): same stream as `create_rand(N)` on the host (solver.py:211), so the run is
+    bit-identical to the host-noise path, chunk after chunk, and the host generator ends up in the
+    same state."""
+    nt = 25
+    runs = {}
+    for dev in (True, False):
+        p = make(N, nt, engine, jitter=0.02)
+        s = chsimpy_amd.Solver(p)
+        s.device_rng = dev
+        s.prepare()
+        s.solve_or_resume(10)
+        sol = s.solve_or_resume(nt - 10)
+        runs[dev] = (sol.U.copy(), sol.timedata.data().copy(), s._pcg.bit_generator.state['state']['state'])
+        s.close()
+    assert runs[True][2] == runs[False][2]                      # generator state
+    assert np.array_equal(runs[True][1], runs[False][1])        # every recorded scalar
+    assert np.array_equal(runs[True][0], runs[False][0])        # the field
 
 
 def test_nan_raises_assertion_like_the_reference(gpu):
