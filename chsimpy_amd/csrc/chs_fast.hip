@@ -155,6 +155,9 @@ __device__ __forceinline__ void stagger_start() {
 #ifndef CHS_ROW_LDS_PAD
 #define CHS_ROW_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower the row kernels' occupancy
 #endif
+#ifndef CHS_ROW_TW_LDS
+#define CHS_ROW_TW_LDS 0  // fused row kernel: middle-pass twiddles from LDS (needs CHS_ROW_PADL=4 to keep 4 workgroups per CU)
+#endif
 // ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
 #ifndef CHS_COL_PARK
 #define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
@@ -178,6 +181,12 @@ __device__ __forceinline__ void stagger_start() {
 __device__ __forceinline__ int launder(int x) {
   asm volatile("" : "+v"(x));
   return x;
+}
+
+// elements of the middle-pass twiddle tables twa | twb (contiguous, build_tables): what the fused row kernel can afford in LDS
+template <class C>
+constexpr int row_tw_elems() {
+  return 2 * ((C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
 }
 
 // ---------------------------------------------------------------------------
@@ -269,6 +278,18 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
     if constexpr (C::WAVE_LOCAL) __syncthreads();  // (no block barrier before the pointwise part otherwise)
   }
+  // middle-pass twiddles (twa | twb) from LDS where the row kernel has room for them (CHS_ROW_TW_LDS)
+  FTables<T> tbp = tb;
+  if constexpr (DIAG && FUSE && CHS_ROW_TW_LDS && !C::WAVE_LOCAL) {
+    T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0));
+    constexpr int NTW = row_tw_elems<C>();
+    for (int i = 2 * threadIdx.x; i < NTW; i += 2 * C::THREADS) {
+      if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(ltw + i) = *reinterpret_cast<const double2*>(tb.twa + i);
+      else *reinterpret_cast<float2*>(ltw + i) = *reinterpret_cast<const float2*>(tb.twa + i);
+    }
+    tbp.twa = ltw;
+    tbp.twb = ltw + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
+  }
   const int row0 = row_of_block<C>(blockIdx.x);
   const int row = row0 + sub;
   T* scr = lds + (size_t)sub * C::SCR;
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     for (int t = 0; t < 4; ++t) y[t] = T2[tile_addr<C>(row, idx[t])];
   }, [](int, const int*, T*, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
-  inv_passes<C>(re, im, scr, tb, launder(l));
+  inv_passes<C>(re, im, scr, tbp, launder(l));
   if constexpr (DIAG && FUSE) STAMP(0, 2);
   __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
   T* urow = U + (size_t)row * C::N;
@@ -428,7 +449,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   if constexpr (DIAG && FUSE) STAMP(0, 4);
   if constexpr (FUSE) {
     __builtin_amdgcn_sched_barrier(0);
-    fwd_passes<C>(re, im, scr, tb, launder(l));
+    fwd_passes<C>(re, im, scr, tbp, launder(l));
     if constexpr (DIAG && FUSE) STAMP(0, 5);
     __builtin_amdgcn_sched_barrier(0);
     // (CHS_ROW_PIPE: twiddles of the next slot ahead of this slot's stores -- measured slower here)
@@ -816,7 +837,8 @@ static FTables<T> get_tables(Engine* E) {
 template <class C, class CC = C>
 struct Launch {
   using T = typename C::T;
-  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0) + CHS_ROW_LDS_PAD;
+  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0) +
+                                    (CHS_ROW_TW_LDS ? (size_t)row_tw_elems<C>() * sizeof(T) : 0) + CHS_ROW_LDS_PAD;
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
   static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && C::R0 == 8;
   // + the parking area of half a hat_U column per lane (k_col<MODE_STEP>)
@@ -928,7 +950,10 @@ using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 #define CHS_ROW_THREADS 256
 #endif
 // row kernels: CHS_ROW_THREADS/128 rows per workgroup, tiles of 4 columns
-using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS_ROW_WPS, 4>;
+#ifndef CHS_ROW_PADL
+#define CHS_ROW_PADL 16
+#endif
+using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, CHS_ROW_PADL, CHS_ROW_WPS, 4>;
 // k_col runs best with the full register file of two waves per SIMD (no spills; the compiler
 // uses the room to keep more loads in flight): measured 305 -> 191 us per launch
 #ifndef CHS_COL_WPS
