@@ -25,7 +25,7 @@ DTYPES = {'float64': CHS_F64, 'f64': CHS_F64, 'float32': CHS_F32, 'f32': CHS_F32
 
 # every symbol include/chs_hip.h declares
 SYMBOLS = (
-    'chs_create', 'chs_destroy', 'chs_set_U', 'chs_get_U', 'chs_prepare', 'chs_step_n',
+    'chs_create', 'chs_destroy', 'chs_set_U', 'chs_init_U_pcg64', 'chs_get_U', 'chs_prepare', 'chs_step_n',
     'chs_get_state', 'chs_set_state', 'chs_set_jitter_noise', 'chs_set_jitter_pcg64', 'chs_dctn', 'chs_get_mu', 'chs_test_math',
     'chs_engine', 'chs_kernel_name', 'chs_profile_steps', 'chs_last_step_ms',
     'chs_last_error', 'chs_version',
@@ -78,6 +78,7 @@ def load():
     lib.chs_set_state.argtypes = [C.c_void_p, C.POINTER(chs_state)]
     lib.chs_set_jitter_noise.argtypes = [C.c_void_p, C.c_double, dp]
     lib.chs_set_jitter_pcg64.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.chs_init_U_pcg64.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.chs_dctn.argtypes = [C.c_void_p, dp, dp, C.c_int]
     lib.chs_get_mu.argtypes = [C.c_void_p, dp]
     lib.chs_engine.argtypes = [C.c_void_p]
@@ -195,6 +196,13 @@ class Engine:
         else:
             noise = _as_f64(noise, (self.N, self.N))
             self._check(self.lib.chs_set_jitter_noise(self._h, float(jitter), _dptr(noise)), 'chs_set_jitter_noise')
+
+    def init_U_pcg64(self, base, scale, state, inc):
+        """U = base + scale*(rand - 0.5) drawn on the device from numpy's PCG64 stream (chs_init_U_pcg64)."""
+        m64 = (1 << 64) - 1
+        st = (C.c_uint64 * 2)((int(state) >> 64) & m64, int(state) & m64)
+        ic = (C.c_uint64 * 2)((int(inc) >> 64) & m64, int(inc) & m64)
+        self._check(self.lib.chs_init_U_pcg64(self._h, float(base), float(scale), st, ic), 'chs_init_U_pcg64')
 
     def set_jitter_pcg64(self, jitter, state, inc):
         """Jitter noise drawn on the device from numpy's PCG64 stream: `state`, `inc` = the two 128-bit

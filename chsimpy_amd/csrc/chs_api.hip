@@ -385,6 +385,19 @@ extern "C" const char* chs_kernel_name(chs_handle h, int slot) {
   return E->engine == CHS_ENGINE_DIRECT ? direct[slot] : fast[slot];
 }
 
+extern "C" int chs_init_U_pcg64(chs_handle h, double base, double scale, const uint64_t state[2], const uint64_t inc[2]) {
+  Engine* E = (Engine*)h;
+  if (!E || !state || !inc) { chs_set_error("chs_init_U_pcg64: null argument"); return CHS_EINVAL; }
+  CHS_HIP(hipSetDevice(E->hc.device));
+  const unsigned long long st[2] = {state[0], state[1]}, ic[2] = {inc[0], inc[1]};
+  const int rc = chs_launch_init_pcg(E, base, scale, st, ic);
+  if (rc) return rc;
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  E->have_U = true;
+  E->hat_valid = false;
+  return CHS_OK;
+}
+
 extern "C" int chs_set_jitter_pcg64(chs_handle h, double jitter, const uint64_t state[2], const uint64_t inc[2]) {
   Engine* E = (Engine*)h;
   if (!E || !state || !inc) { chs_set_error("chs_set_jitter_pcg64: null argument"); return CHS_EINVAL; }

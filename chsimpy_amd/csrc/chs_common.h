@@ -225,7 +225,8 @@ int chs_launch_sum(Engine* E, int ignore_halt);  // meanU <- mean(dU)
 int chs_launch_diag(Engine* E, int ignore_halt);  // dU -> diag partials
 int chs_launch_fin(Engine* E, int prepare_mode, int fused = 0);
 int chs_launch_jitter(Engine* E);
-int chs_launch_jitter_pcg(Engine* E);  // U += jitter*(2*r-1), r from the PCG64 stream; advances E->pcgState by N*N
+int chs_launch_jitter_pcg(Engine* E);
+int chs_launch_init_pcg(Engine* E, double base, double scale, const unsigned long long state[2], const unsigned long long inc[2]);  // U += jitter*(2*r-1), r from the PCG64 stream; advances E->pcgState by N*N
 int chs_pointwise_alloc(Engine* E);
 void chs_pointwise_free(Engine* E);
 

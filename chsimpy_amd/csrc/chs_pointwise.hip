@@ -343,14 +343,14 @@ __host__ __device__ inline void chs_pcg_jump(chs_u128 delta, chs_u128 inc, chs_u
     delta >>= 1;
   }
 }
-template <typename T>
-__global__ __launch_bounds__(PW_THREADS) void k_jitter_pcg(T* __restrict__ U, double jitter, size_t total,
+template <typename T, bool INIT>
+__global__ __launch_bounds__(PW_THREADS) void k_jitter_pcg(T* __restrict__ U, double jitter, double base, size_t total,
                                                            unsigned long long s_hi, unsigned long long s_lo,
                                                            unsigned long long i_hi, unsigned long long i_lo,
                                                            unsigned long long m_hi, unsigned long long m_lo,
                                                            unsigned long long p_hi, unsigned long long p_lo,
                                                            const DevState* __restrict__ st) {
-  if (st->halt) return;
+  if (!INIT && st->halt) return;
   const size_t tt = (size_t)gridDim.x * PW_THREADS, t = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
   const chs_u128 inc = ((chs_u128)i_hi << 64) | i_lo;
   const chs_u128 multTT = ((chs_u128)m_hi << 64) | m_lo, plusTT = ((chs_u128)p_hi << 64) | p_lo;
@@ -365,34 +365,51 @@ __global__ __launch_bounds__(PW_THREADS) void k_jitter_pcg(T* __restrict__ U, do
     const double r = (double)(o >> 11) * (1.0 / 9007199254740992.0);
     {
 #pragma clang fp contract(off)
-      U[i] = (T)((double)U[i] + jitter * (2.0 * r - 1.0));
+      if constexpr (INIT) U[i] = (T)(base + jitter * (r - 0.5));  // solver.py:82 (jitter = the scale here)
+      else U[i] = (T)((double)U[i] + jitter * (2.0 * r - 1.0));
     }
     s = s * multTT + plusTT;
   }
 }
 
-int chs_launch_jitter_pcg(Engine* E) {
+static int launch_pcg(Engine* E, bool init, double a, double base, const unsigned long long st[2], const unsigned long long ic[2]) {
   const size_t total = (size_t)E->N * E->N;
   int blocks = (int)((total + PW_THREADS * 64 - 1) / ((size_t)PW_THREADS * 64));  // 64 draws per thread
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
-  const chs_u128 state = ((chs_u128)E->pcgState[0] << 64) | E->pcgState[1];
-  const chs_u128 inc = ((chs_u128)E->pcgInc[0] << 64) | E->pcgInc[1];
-  chs_u128 mtt, ptt, mall, pall;
+  const chs_u128 inc = ((chs_u128)ic[0] << 64) | ic[1];
+  chs_u128 mtt, ptt;
   chs_pcg_jump((chs_u128)blocks * PW_THREADS, inc, mtt, ptt);
+  const unsigned long long mh = (unsigned long long)(mtt >> 64), ml = (unsigned long long)mtt;
+  const unsigned long long ph = (unsigned long long)(ptt >> 64), pl = (unsigned long long)ptt;
   chs_slot_begin(E, SLOT_MISC);
-  DISPATCH_T(E,
-    (k_jitter_pcg<double><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, E->jitter, total, E->pcgState[0], E->pcgState[1],
-        E->pcgInc[0], E->pcgInc[1], (unsigned long long)(mtt >> 64), (unsigned long long)mtt,
-        (unsigned long long)(ptt >> 64), (unsigned long long)ptt, E->dState)),
-    (k_jitter_pcg<float><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, E->jitter, total, E->pcgState[0], E->pcgState[1],
-        E->pcgInc[0], E->pcgInc[1], (unsigned long long)(mtt >> 64), (unsigned long long)mtt,
-        (unsigned long long)(ptt >> 64), (unsigned long long)ptt, E->dState)));
+  if (init) {
+    DISPATCH_T(E,
+      (k_jitter_pcg<double, true><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState)),
+      (k_jitter_pcg<float, true><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState)));
+  } else {
+    DISPATCH_T(E,
+      (k_jitter_pcg<double, false><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState)),
+      (k_jitter_pcg<float, false><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState)));
+  }
   chs_slot_end(E, SLOT_MISC);
   CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
+int chs_launch_init_pcg(Engine* E, double base, double scale, const unsigned long long state[2], const unsigned long long inc[2]) {
+  return launch_pcg(E, true, scale, base, state, inc);
+}
+
+int chs_launch_jitter_pcg(Engine* E) {
+  const int rc = launch_pcg(E, false, E->jitter, 0.0, E->pcgState, E->pcgInc);
+  if (rc) return rc;
   // the generator moves on by one field per step, whether or not a stop has turned the kernel into a
   // no-op: the caller re-seeds from its own generator at the next call
-  chs_pcg_jump((chs_u128)total, inc, mall, pall);
+  const chs_u128 state = ((chs_u128)E->pcgState[0] << 64) | E->pcgState[1];
+  const chs_u128 inc = ((chs_u128)E->pcgInc[0] << 64) | E->pcgInc[1];
+  chs_u128 mall, pall;
+  chs_pcg_jump((chs_u128)E->N * E->N, inc, mall, pall);
   const chs_u128 next = state * mall + pall;
   E->pcgState[0] = (unsigned long long)(next >> 64); E->pcgState[1] = (unsigned long long)next;
   return CHS_OK;

@@ -36,8 +36,9 @@ class Solver:
 
         self.create_rand = None
         self._pcg = None
-        self.device_rng = True   # draw the jitter noise on the device when the generator is numpy's PCG64
-        self.U_init = None
+        self._pcg_state0 = None  # the default generator's state before the start field was drawn
+        self.device_rng = True   # draw start field and jitter noise on the device when the generator is numpy's PCG64
+        self._U_init = None
         # initial concentration field, solver.py:59-82
         if U_init is not None:
             if U_init.shape == (N, N):
@@ -62,8 +63,27 @@ class Solver:
             rng = np.random.Generator(np.random.PCG64(params.seed))
             self.create_rand = lambda n: rng.random((n, n))
             self._pcg = rng   # the device can continue this stream itself (jitter, solve_or_resume)
-        if self.U_init is None:
-            self.U_init = params.XXX + (params.XXX * 0.01 * (self.create_rand(N) - 0.5))
+            # The start field XXX + XXX*0.01*(rng.random((N,N)) - 0.5) (solver.py:78-82) is not drawn
+            # here: prepare() lets the device draw it from the same stream (no N*N*8-byte upload), the
+            # attribute U_init computes it on the host when somebody looks at it.  The generator moves
+            # on by the N*N draws either way.
+            self._pcg_state0 = rng.bit_generator.state
+            rng.bit_generator.advance(N * N)
+        if self._U_init is None and self._pcg_state0 is None:
+            self._U_init = params.XXX + (params.XXX * 0.01 * (self.create_rand(N) - 0.5))
+
+    @property
+    def U_init(self):
+        if self._U_init is None and self._pcg_state0 is not None:
+            g = np.random.Generator(np.random.PCG64())
+            g.bit_generator.state = self._pcg_state0
+            p = self.params
+            self._U_init = p.XXX + (p.XXX * 0.01 * (g.random((p.N, p.N)) - 0.5))
+        return self._U_init
+
+    @U_init.setter
+    def U_init(self, value):
+        self._U_init = value
 
     # -- engine ----------------------------------------------------------------
     def _consts(self):
@@ -123,16 +143,25 @@ class Solver:
 
     # -- solver.py:84-135 ----------------------------------------------------------
     def prepare(self):
-        U = self.U_init.copy()
         N = self.params.N
-        assert (U.shape == (N, N))
         eng = self._get_engine()
         self._push_state()
-        eng.set_U(U)
+        on_device = self._U_init is None and self._pcg_state0 is not None and self.device_rng
+        if on_device:
+            st = self._pcg_state0['state']
+            p = self.params
+            eng.init_U_pcg64(p.XXX, p.XXX * 0.01, st['state'], st['inc'])
+            U = None
+        else:
+            U = self.U_init.copy()
+            assert (U.shape == (N, N))
+            eng.set_U(U)
         row = eng.prepare()
         data = TimeData()
         data.insert(it=0, delt=row[8], E=row[1], E2=row[2], SA=0, domtime=0, Ra=row[5], L2=0, PS=row[7])
         self.solution.U = U
+        if on_device:
+            self.solution._U_fetch = eng.get_U   # downloaded when somebody looks at solution.U
         self.solution.timedata = data
         self.solution.tau0 = 0.0
         self.solution.t0 = 0.0

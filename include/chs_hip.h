@@ -102,6 +102,11 @@ int chs_destroy(chs_handle h);
  * Replaces `U = self.U_init.copy()` (solver.py:85) and `U = self.solution.U`
  * (solver.py:158). */
 int chs_set_U(chs_handle h, const double* host_U);
+/* The same without a host array, for the reference's default start field (solver.py:78-82):
+ * U[r][c] = base + scale * (rand - 0.5), rand = draw r*N+c of numpy's PCG64 `Generator.random`
+ * started from the 128-bit `state` / `inc` ({high word, low word}) -- bit-identical to
+ * `XXX + XXX*0.01*(rng.random((N,N)) - 0.5)` with base = XXX, scale = XXX*0.01. */
+int chs_init_U_pcg64(chs_handle h, double base, double scale, const uint64_t state[2], const uint64_t inc[2]);
 /* Download the current field (solver.py:251 `self.solution.U = U`). */
 int chs_get_U(chs_handle h, double* host_U);
 

@@ -158,6 +158,25 @@ def test_resume_chunks_match_oracle_chunks(gpu):
     s.close()
 
 
+@pytest.mark.parametrize("N,engine", [(100, 'direct'), (512, 'fast')])
+def test_start_field_drawn_on_the_device(gpu, N, engine):
+    """Default generator: prepare() lets the device draw XXX + XXX*0.01*(rand - 0.5) (solver.py:78-82)
+    from numpy's PCG64 stream -- bit for bit what the host expression gives -- instead of uploading it."""
+    p = make(N, 3, engine)
+    s = chsimpy_amd.Solver(p)
+    assert s._U_init is None                       # not drawn on the host
+    s.prepare()
+    on_dev = s._engine.get_U()
+    assert s._U_init is None
+    rng = np.random.Generator(np.random.PCG64(p.seed))
+    expect = p.XXX + (p.XXX * 0.01 * (rng.random((N, N)) - 0.5))
+    assert np.array_equal(on_dev, expect)
+    assert np.array_equal(s.U_init, expect)         # the attribute, computed on demand
+    assert np.array_equal(s.solution.U, expect)
+    assert s._pcg.bit_generator.state == rng.bit_generator.state   # the generator moved on by N*N draws
+    s.close()
+
+
 def test_solution_U_is_downloaded_on_demand(gpu):
     """Solution.U (solution.py:21) is fetched from the device when it is looked at, not after every
     chunk: chunked driving (simulator.py:62-81) then costs no N*N*8-byte PCIe transfer per chunk."""
