@@ -172,13 +172,6 @@ def run_ensemble(init_params, ep, run_fn=None, U_init=None, dist=None, rank=0, w
     partly idle between its latency-bound kernels, two or three concurrent runs fill the gaps."""
     rand_values, A_list, nr_items = make_rand_values(ep)
     if run_fn is None:
-        if (U_init is None and getattr(init_params, 'generator', 'uniform') not in ('lcg', 'sobol', 'simplex')
-                and not (init_params.jitter is not None and 0.0 < init_params.jitter < 0.1)):
-            # every member starts from the same field (same seed, same N; only A0/A1 differ): draw it
-            # once per rank instead of once per member (jitter runs keep their own generator)
-            from .solver import default_U_init
-            U_init = default_U_init(init_params)
-
         def run_fn(run_id, p, rv, al):
             return run_experiment_gpu(run_id, p, rv, al, U_init)
     ids = my_run_ids(nr_items, rank, world)

@@ -15,13 +15,6 @@ from .solution import Solution
 from .timedata import TimeData
 
 
-def default_U_init(params):
-    """The start field of the default generator (solver.py:78-82): numpy PCG64(seed), uniform.  The
-    members of an ensemble share seed and N (experiment.py:87-101), hence this field."""
-    rng = np.random.Generator(np.random.PCG64(params.seed))
-    return params.XXX + (params.XXX * 0.01 * (rng.random((params.N, params.N)) - 0.5))
-
-
 class Solver:
     def __init__(self, params=None, U_init=None):
         self.params = params

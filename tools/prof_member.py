@@ -6,8 +6,7 @@ p = chsimpy_amd.Parameters()
 p.N, p.ntmax, p.full_sim, p.kappa_tilde, p.file_id = 2048, 400, True, 0.0002989112919661156, '/tmp/ens'
 ep = ex.ExperimentParams(); ep.runs = 4
 rv, al, n = ex.make_rand_values(ep)
-from chsimpy_amd.solver import default_U_init
-U0 = default_U_init(p)
+U0 = None   # every member draws the (shared) start field on the device
 ex.run_experiment_gpu(0, p, rv, al, U0, postprocess=False)   # warm
 pr = cProfile.Profile(); pr.enable()
 t0=time.time()
