@@ -7,8 +7,9 @@ A "step" is one iteration of chsimpy/solver.py:165-249 (pointwise chemical
 potential -> 2-D DCT-II -> spectral update -> inverse DCT -> energy/statistics
 record) on an N x N fp64 grid resident in HBM.  Workload at --gpus 1: BASELINE.json
 configs[2] (N=4096, fp64, synthetic U_init of solver.py:78-82 with seed 2023).
-With --gpus G > 1 every rank (one process per GPU, RCCL) advances its own
-independent member of a Monte-Carlo ensemble (chsimpy/experiment.py:84-126, one run
+With --gpus G > 1 the script starts G ranks itself (or runs as one of the ranks a
+launcher such as torch.distributed.run started); every rank (one process per GPU,
+RCCL) advances its own independent member of a Monte-Carlo ensemble (chsimpy/experiment.py:84-126, one run
 per GPU, A0/A1 scaled per rank) -- weak scaling, no data-path collective; the only
 collective is the all_gather of the per-run energy scalars at the end.
 
@@ -45,6 +46,8 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=0, help='0 = size the CPU sample automatically')
     ap.add_argument('--profile-steps', type=int, default=20)
     ap.add_argument('--energy-stop', action='store_true', help='full_sim=False (the reference default: stop at the E2 maximum); not the headline workload')
+    ap.add_argument('--dry-run', action='store_true', help='launcher/collective rehearsal without device work (CPU tests of the '
+                    'N>1 path); the line it prints is marked as such and is not a measurement')
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 1000 if a.energy_stop else 5000
@@ -97,8 +100,74 @@ def cpu_baseline(N, steps_hint):
                       f'{dt:.1f} s wall, BLAS limited to 1 thread; host has {os.cpu_count()} logical cores'}
 
 
+def dry_run(a, rank, world, dist, coll_dev):
+    """The N>1 protocol without device work: barrier, timed region (a sleep stands in for the steps),
+    MAX over ranks, the all_gather of the per-run scalars, one JSON line from rank 0."""
+    import torch
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.001 * a.steps)
+    dt = time.perf_counter() - t0
+    energies = [[float(rank), float(world)]]
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        mine = torch.tensor(energies[0], dtype=torch.float64, device=coll_dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        energies = [[float(v[0]), float(v[1])] for v in allv]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': metric_name(a.grid, a.dtype), 'value': None, 'unit': 'timesteps/s', 'n_gpus': world,
+                          'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': None, 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'data': 'dry-run (launcher rehearsal, no device work: not a measurement)',
+                          'energies_last_step': energies}), flush=True)
+
+
+def metric_name(N, dtype):
+    t = 'fp64' if dtype in ('float64', 'f64') else 'fp32'
+    return f'timesteps/sec at N={N} {t}; achieved HBM GB/s vs MI355X peak'
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, one process
+    per GPU, like the reference's ensemble starts its own worker pool (chsimpy/experiment.py:197-216).
+    This parent has not touched the GPU (no torch.cuda, no engine): the ranks are ordinary child
+    processes (never an exec of a process that has initialised the device).  Rank 0's JSON line is
+    forwarded; any failing rank fails the run."""
+    import socket
+    import subprocess
+    import __graft_entry__ as g
+    if not a.dry_run:
+        g.build_hip()  # once, before the ranks start (hipcc only; no device needed)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = [ln for ln in (out0 or '').splitlines() if ln.startswith('{')]
+    if any(codes) or not line:
+        sys.stderr.write(f'bench.py: ranks exited with {codes}\n')
+        if out0:
+            sys.stderr.write(out0)
+        sys.exit(1)
+    print(line[-1], flush=True)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'RANK' not in os.environ:
+        return launch_ranks(a)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -114,11 +183,13 @@ def main():
     coll_dev = 'cpu' if backend == 'gloo' else f'cuda:{device}'
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(device)
         if backend == 'nccl':
+            torch.cuda.set_device(device)
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', device))
         else:
             dist.init_process_group(backend=backend)
+    if a.dry_run:
+        return dry_run(a, rank, world, dist, coll_dev)
 
     import __graft_entry__ as g
     if rank == 0:
@@ -207,7 +278,7 @@ def main():
                                    'achieved': round(bytes_step / (ms_per_step * 1e-3) / 1e9, 1),
                                    'frac': round(bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
         out = {
-            'metric': 'timesteps/sec at N=4096 fp64; achieved HBM GB/s vs MI355X peak',
+            'metric': metric_name(N, a.dtype),
             'value': round(value, 3), 'unit': 'timesteps/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,

@@ -90,10 +90,6 @@ def load():
     lib.chs_last_step_ms.restype = C.c_double
     lib.chs_last_error.restype = C.c_char_p
     lib.chs_version.restype = C.c_char_p
-    for s in SYMBOLS:
-        f = getattr(lib, s)
-        if f.restype is C.c_int:
-            pass
     _lib = lib
     return lib
 

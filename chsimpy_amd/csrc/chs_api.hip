@@ -2,6 +2,7 @@
 // traffic and the per-timestep launch sequence (chsimpy/solver.py:84-252).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -56,16 +57,13 @@ static void timer_harvest(Engine* E) {
 }
 
 // ---------------------------------------------------------------------------
-static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+#define CHS_ROWS_RING 65536  // rows of the device ring (4.7 MB), a multiple of the batch size of run_steps
 
-static int ensure_rows(Engine* E, long long n) {
-  if (n < 1) n = 1;
-  if (n <= E->rowsCap) return CHS_OK;
-  if (n < 65536) n = 65536;  // (4.7 MB) no reallocation -- a device-wide sync -- inside ordinary calls
-  if (E->dRows) hipFree(E->dRows);
-  E->dRows = nullptr;
-  CHS_HIP(hipMalloc(&E->dRows, sizeof(double) * 9 * (size_t)n));
-  E->rowsCap = n;
+// timedata rows of the running call: one allocation for the handle's lifetime, used as a ring (run_steps)
+static int ensure_rows(Engine* E) {
+  if (E->dRows) return CHS_OK;
+  CHS_HIP(hipMalloc(&E->dRows, sizeof(double) * 9 * (size_t)CHS_ROWS_RING));
+  E->rowsCap = CHS_ROWS_RING;
   return CHS_OK;
 }
 
@@ -80,6 +78,8 @@ static void free_engine(Engine* E) {
   for (auto e : E->timer.pool) hipEventDestroy(e);
   if (E->evA) hipEventDestroy(E->evA);
   if (E->evB) hipEventDestroy(E->evB);
+  for (int i = 0; i < 4; ++i) if (E->evPoll[i]) hipEventDestroy(E->evPoll[i]);
+  if (E->hState) hipHostFree(E->hState);
   if (E->stream) hipStreamDestroy(E->stream);
   delete E;
 }
@@ -128,6 +128,8 @@ extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle*
   TRY_HIP(hipStreamCreateWithFlags(&E->stream, hipStreamNonBlocking));
   TRY_HIP(hipEventCreate(&E->evA));
   TRY_HIP(hipEventCreate(&E->evB));
+  for (int i = 0; i < 4; ++i) TRY_HIP(hipEventCreateWithFlags(&E->evPoll[i], hipEventDisableTiming));
+  TRY_HIP(hipHostMalloc((void**)&E->hState, sizeof(DevState) * 5, hipHostMallocDefault));
   const size_t nb = (size_t)N * N * E->esz;
   TRY_HIP(hipMalloc(&E->dU, nb));
   TRY_HIP(hipMalloc(&E->dMU, nb));
@@ -140,10 +142,15 @@ extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle*
   DevState s0;
   memset(&s0, 0, sizeof s0);
   s0.delt = c->delt;
+  s0.delt_coef = c->delt;
   s0.lam1 = c->delt / d.delx2;
   s0.lam2 = c->kappa_tilde * s0.lam1 / d.delx2;
   TRY_HIP(hipMemcpy(E->dState, &s0, sizeof s0, hipMemcpyHostToDevice));
-  if ((rc = ensure_rows(E, 64))) return fail(rc);
+  if ((rc = ensure_rows(E))) return fail(rc);
+  if (const char* bs = getenv("CHS_BATCH_STEPS")) {  // test hook: small batches exercise the polling path
+    const long v = atol(bs);
+    if (v >= 1 && v <= CHS_ROWS_RING / 8) E->batchSteps = (int)v;
+  }
   if ((rc = chs_pointwise_alloc(E))) return fail(rc);
   if (eng == CHS_ENGINE_DIRECT) rc = chs_direct_init(E); else rc = chs_fast_init(E);
   if (rc) return fail(rc);
@@ -226,8 +233,7 @@ extern "C" int chs_set_state(chs_handle h, const chs_state* in) {
   s.delt = in->delt; s.time_delta_sum = in->time_delta_sum; s.time_passed = in->time_passed;
   s.tau0 = in->tau0; s.t0 = in->t0; s.computed_steps = in->computed_steps;
   s.skip_check = in->skip_check; s.stop_reason = in->stop_reason;
-  s.lam1 = s.delt / E->dc.delx2;
-  s.lam2 = E->dc.kappa_tilde * s.lam1 / E->dc.delx2;
+  // (the coefficients follow params.delt, not this delt: every call reloads them, k_call_begin)
   CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
   return CHS_OK;
 }
@@ -288,26 +294,43 @@ static int one_step(Engine* E, bool first, bool last) {
   return CHS_OK;
 }
 
+// Steps are issued in batches.  Behind every batch the device state is copied into a pinned slot;
+// before batch b+1 goes out, the slot behind batch b-1 is looked at (the device is then busy with
+// batch b, so it never idles): once `halt` is up -- energy stop, time limit, NaN -- nothing more is
+// issued.  The reference's defaults are ntmax = 1e6 with full_sim = False (parameters.py:42,50): a run
+// that stops after a thousand steps must not queue three million empty launches behind the stop.
+// The rows of finished batches are copied out of the device ring as they complete.
+#ifndef CHS_BATCH_STEPS
+#define CHS_BATCH_STEPS 1024
+#endif
+static_assert(CHS_ROWS_RING % CHS_BATCH_STEPS == 0 && CHS_ROWS_RING >= 8 * CHS_BATCH_STEPS, "ring and batch size");
+
+static int copy_rows_out(Engine* E, double* rows, int64_t from, int64_t to) {
+  // ring -> caller's array, rows [from, to); at most two pieces
+  while (from < to) {
+    const int64_t slot = from % E->rowsCap;
+    int64_t n = to - from;
+    if (slot + n > E->rowsCap) n = E->rowsCap - slot;
+    CHS_HIP(hipMemcpy(rows + from * 9, E->dRows + slot * 9, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost));
+    from += n;
+  }
+  return CHS_OK;
+}
+
 static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t* steps_done, bool profile) {
   if (!E->prepared) { chs_set_error("chs_step_n: not prepared (solver.py:139)"); return CHS_ESTATE; }
   if (nsteps < 0) nsteps = 0;
   CHS_HIP(hipSetDevice(E->hc.device));
   int rc;
-  if ((rc = ensure_rows(E, nsteps))) return rc;
-  // a new call re-arms the loop: `halt` only lives inside one solve_or_resume
-  {
-    DevState s;
-    CHS_HIP(hipStreamSynchronize(E->stream));
-    CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
-    s.halt = 0; s.nan_flag = 0; s.rows_written = 0;
-    CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
-  }
+  if ((rc = ensure_rows(E))) return rc;
   if (profile) {
     E->timer.on = true;
     for (int i = 0; i < CHS_NKERNELS; ++i) { E->timer.ms[i] = 0; E->timer.calls[i] = 0; }
   }
   CHS_HIP(hipEventRecord(E->evA, E->stream));
-  E->timer.on = false;  // the entry transform is not a per-step kernel
+  E->timer.on = false;  // the entry work is not a per-step kernel
+  // a new call re-arms the loop and reloads the coefficients of params.delt (k_call_begin)
+  if ((rc = chs_launch_call_begin(E))) return rc;
   if (!((flags & CHS_STEP_CARRY_HAT) && E->hat_valid)) {
     if ((rc = enter(E))) return rc;
   }
@@ -317,18 +340,42 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   if (fused && nsteps > 0) {
     if ((rc = chs_fast_prologue(E))) { E->timer.on = false; return rc; }
   }
-  for (int64_t s = 0; s < nsteps; ++s) {
-    if ((rc = one_step(E, s == 0, s == nsteps - 1))) { E->timer.on = false; return rc; }
-    if (profile && (s % 32) == 31) timer_harvest(E);
+  int64_t issued = 0, copied = 0;
+  int batch = 0;
+  bool stopped = false;
+  while (issued < nsteps && !stopped) {
+    int64_t nb = nsteps - issued;
+    if (nb > E->batchSteps) nb = E->batchSteps;
+    for (int64_t s = issued; s < issued + nb; ++s) {
+      if ((rc = one_step(E, s == 0, s == nsteps - 1))) { E->timer.on = false; return rc; }
+      if (profile && (s % 32) == 31) timer_harvest(E);
+    }
+    issued += nb;
+    if (issued < nsteps) {
+      const int slot = 1 + (batch & 3);
+      CHS_HIP(hipMemcpyAsync(&E->hState[slot], E->dState, sizeof(DevState), hipMemcpyDeviceToHost, E->stream));
+      CHS_HIP(hipEventRecord(E->evPoll[batch & 3], E->stream));
+      if (batch >= 1) {
+        const int prev = (batch - 1) & 3;
+        CHS_HIP(hipEventSynchronize(E->evPoll[prev]));
+        const DevState& ps = E->hState[1 + prev];
+        if (rows && ps.rows_written > copied) {
+          if ((rc = copy_rows_out(E, rows, copied, ps.rows_written))) return rc;
+          copied = ps.rows_written;
+        }
+        if (ps.halt) stopped = true;
+      }
+      ++batch;
+    }
   }
   if (profile) { timer_harvest(E); E->timer.on = false; }
   CHS_HIP(hipEventRecord(E->evB, E->stream));
+  CHS_HIP(hipMemcpyAsync(&E->hState[0], E->dState, sizeof(DevState), hipMemcpyDeviceToHost, E->stream));
   CHS_HIP(hipStreamSynchronize(E->stream));
   float ms = 0.f;
   CHS_HIP(hipEventElapsedTime(&ms, E->evA, E->evB));
   E->lastStepMs = ms;
-  DevState s;
-  CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+  const DevState s = E->hState[0];
   if (s.halt && s.stop_reason != CHS_STOP_NONE && !s.nan_flag && fused && !E->storeU && s.rows_written < nsteps) {
     // the energy rule or the time limit ended the call before its last step and the row kernel has
     // been keeping U in registers: hat_U is that of the last completed step, rebuild the field from
@@ -344,8 +391,10 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   int64_t done = s.rows_written;
   if (done > nsteps) done = nsteps;
   if (steps_done) *steps_done = done;
-  if (rows && done > 0) {
-    CHS_HIP(hipMemcpy(rows, E->dRows, sizeof(double) * 9 * (size_t)done, hipMemcpyDeviceToHost));
+  if (rows && done > copied) {
+    if ((rc = copy_rows_out(E, rows, copied, done))) return rc;
+  }
+  if (rows) {
     // solver.py:230 `domtime = self.time_passed ** (1 / 3)` with the host libm
     for (int64_t i = 0; i < done; ++i) rows[i * 9 + 4] = pow(rows[i * 9 + 4], 1.0 / 3.0);
   }

@@ -24,7 +24,10 @@ struct DevState {
   double E2_0, E2_prev;   // timedata.py:63 operands
   double L2_cur;          // ||EnergieEut||_F / N^2 of the running step (solver.py:225)
   double meanU;           // mean of the field the next statistics sweep refers to (solver.py:223)
-  double lam1, lam2;      // utils.py:41-42 for the current delt
+  double lam1, lam2;      // utils.py:41-42 for delt_coef
+  double delt_coef;       // the delt the coefficient grids CHeig/Seig stand for: params.delt from the entry of
+                          // every solve_or_resume call (solver.py:154-155 reloads solution.Seig/CHeig, which
+                          // solution.py:52-55 built once) until the adaptive step regenerates them (189-193)
   long long computed_steps;  // solver.py:134,240
   long long rows_written;    // rows produced by the running chs_step_n call
   int skip_check;            // solver.py:50,249
@@ -182,6 +185,11 @@ struct Engine {
   bool storeU = true;         // the fused row kernel writes U on intermediate steps (chs_fast_step)
   int tailSet = 0;            // ... on this partial set
   hipEvent_t evA = nullptr, evB = nullptr;
+  // pinned host mirror of the device state: slot 0 = the state at the end of a call, slots 1..4 = the
+  // polls behind the batches of a long call (run_steps)
+  DevState* hState = nullptr;
+  hipEvent_t evPoll[4] = {nullptr, nullptr, nullptr, nullptr};
+  int batchSteps = 1024;      // steps issued between two looks at the device's halt flag (run_steps)
   double lastStepMs = 0.0;
   StepTimer timer;
   std::vector<double> hostTmp;
@@ -220,6 +228,7 @@ struct TailArgs;
 TailArgs chs_tail_args(const Engine* E, int set, int do_pre);  // set < 0: the current partial-sum pointers
 int chs_launch_step_tail(Engine* E, int do_pre);  // fused pipeline: record of step s + time-step control of step s+1
 int chs_launch_pre(Engine* E);                // partials -> state (L2, delt, time)
+int chs_launch_call_begin(Engine* E);         // entry of a solve_or_resume call: re-arm the loop, coefficients of params.delt
 int chs_launch_spectral(Engine* E, const void* hmu);  // dHat <- (dHat + Seig*hmu)/CHeig (natural order)
 int chs_launch_sum(Engine* E, int ignore_halt);  // meanU <- mean(dU)
 int chs_launch_diag(Engine* E, int ignore_halt);  // dU -> diag partials

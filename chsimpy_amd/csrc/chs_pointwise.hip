@@ -97,6 +97,28 @@ __global__ __launch_bounds__(PW_THREADS) void k_pre(DevConsts dc, DevState* __re
 }
 
 // ---------------------------------------------------------------------------
+// k_call_begin (one thread): entry of a solve_or_resume call.  Re-arms the loop (`halt` only lives
+// inside one call) and reloads the coefficients of params.delt: solver.py:154-155 takes
+// solution.Seig/CHeig, which solution.py:52-55 built once from params.delt, whatever self.delt has
+// become -- an adaptive run that is resumed works with them until its step is re-evaluated (189-193).
+// A kernel instead of a host round trip: nothing waits for it.
+// ---------------------------------------------------------------------------
+__global__ void k_call_begin(DevConsts dc, DevState* __restrict__ st) {
+#pragma clang fp contract(off)
+  st->halt = 0; st->nan_flag = 0; st->rows_written = 0;
+  st->delt_coef = dc.delt0;
+  const double lam1 = dc.delt0 / dc.delx2;
+  st->lam1 = lam1;
+  st->lam2 = dc.kappa_tilde * lam1 / dc.delx2;
+}
+
+int chs_launch_call_begin(Engine* E) {
+  k_call_begin<<<1, 1, 0, E->stream>>>(E->dc, E->dState);
+  CHS_HIP(hipGetLastError());
+  return CHS_OK;
+}
+
+// ---------------------------------------------------------------------------
 // k_spectral (direct engine, natural order): hat_U <- (hat_U + Seig*hat_mu)/CHeig
 // ---------------------------------------------------------------------------
 template <typename T>

@@ -18,8 +18,12 @@ __device__ __forceinline__ void pre_update(const DevConsts& dc, DevState* st, do
     else
       delt = delt_new;
     st->delt = delt;
+    st->delt_coef = delt;  // solver.py:189-193: the grids are regenerated for the new step
   }
-  const double lam1 = delt / dc.delx2;  // utils.py:41-42
+  // The grids stand for delt_coef, not delt: a resumed adaptive run keeps its adapted self.delt for the
+  // time bookkeeping below but works with the grids of params.delt until the step is re-evaluated
+  // (solver.py:154-155 against 189-193)
+  const double lam1 = st->delt_coef / dc.delx2;  // utils.py:41-42
   st->lam1 = lam1;
   st->lam2 = dc.kappa_tilde * lam1 / dc.delx2;
   const double tds = st->time_delta_sum + delt;  // solver.py:195-199
@@ -36,8 +40,9 @@ __device__ __forceinline__ void pre_update(const DevConsts& dc, DevState* st, do
 __device__ __forceinline__ void fin_update(const DevConsts& dc, DevState* st, double E, double E2, double PS,
                                            double SA, double Ra, double* __restrict__ rows, long long rowsCap) {
   const long long k = st->rows_written;
-  if (k < rowsCap) {
-    double* row = rows + k * 9;
+  {
+    // a ring: run_steps() copies the rows out batch by batch, long before a slot comes round again
+    double* row = rows + (k % rowsCap) * 9;
     row[0] = (double)st->computed_steps; row[1] = E; row[2] = E2; row[3] = SA;
     row[4] = st->time_passed; row[5] = Ra; row[6] = st->L2_cur; row[7] = PS; row[8] = st->delt;
   }
@@ -156,7 +161,7 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
     if (do_pre && !loc.halt) pre_update(dc, &loc, tot[5], adapt, tot[NV]);
     // write back everything except meanU: when the tail rides in k_col of the NEXT step, that
     // kernel may be storing it at this very moment (it is the only other writer of the state)
-    st->delt = loc.delt; st->time_delta_sum = loc.time_delta_sum; st->time_passed = loc.time_passed;
+    st->delt = loc.delt; st->delt_coef = loc.delt_coef; st->time_delta_sum = loc.time_delta_sum; st->time_passed = loc.time_passed;
     st->tau0 = loc.tau0; st->t0 = loc.t0; st->E2_0 = loc.E2_0; st->E2_prev = loc.E2_prev;
     st->L2_cur = loc.L2_cur; st->lam1 = loc.lam1; st->lam2 = loc.lam2;
     st->computed_steps = loc.computed_steps; st->rows_written = loc.rows_written;

@@ -112,13 +112,12 @@ def run_experiment_gpu(run_id, init_params, rand_values, A_list, U_init=None, po
     simulator.export()
     ca = cb = sa = sb = float('nan')
     if postprocess:
-        try:
-            cgap = utils.get_miscibility_gap(params.R, params.temp, params.B, solution.A0, solution.A1)
-            ca, cb = float(cgap[0]), float(cgap[1])
-            roots = utils.get_roots_of_EPP(params.R, params.temp, solution.A0, solution.A1)
-            sa, sb = float(roots[0]), float(roots[1])
-        except Exception:  # sympy missing or no two roots: keep NaN, the run itself is valid
-            pass
+        # experiment.py:110-112 -- a failure here (sympy missing, no common tangent, not exactly two
+        # spinodal roots) is an error of the run, as in the reference: a silent NaN would poison
+        # -results-agg.csv.  postprocess=False skips the thermodynamic columns explicitly.
+        cgap = utils.get_miscibility_gap(params.R, params.temp, params.B, solution.A0, solution.A1)
+        ca, cb = float(cgap[0]), float(cgap[1])
+        sa, sb = (float(r) for r in utils.get_roots_of_EPP(params.R, params.temp, solution.A0, solution.A1))
     itargmax = int(np.argmax(solution.E2))
     simulator.solver.close(fetch_U=False)   # the record needs scalars only
     return (solution.A0, solution.A1, ca, cb, sa, sb, solution.tau0, solution.t0, itargmax, run_id,
@@ -148,6 +147,14 @@ def gather_records(local, nr_items, rank, world, dist=None, device='cpu'):
             if not np.isnan(row[9]):
                 recs.append(tuple(row.tolist()))
     return sorted(recs, key=lambda r: r[9])
+
+
+def write_metadata(file_id, ep, extra=()):
+    """``<file_id>-metadata.csv`` (experiment.py:193-195): system information followed by the
+    experiment parameters, one ``name, value`` per line."""
+    lines = list(utils.get_system_info()) + list(extra) + utils.vars_to_list(ep)
+    utils.csv_export_list(f"{file_id}-metadata.csv", "\n".join(lines))
+    return f"{file_id}-metadata.csv"
 
 
 def write_results(file_id, records):
@@ -221,12 +228,15 @@ def main(argv=None):
     ep.runs, ep.independent, ep.A_source, ep.A_seed = a.runs, a.independent, a.A_source, a.A_seed
     U_init = utils.csv_import_matrix(p.Uinit_file) if p.Uinit_file else None
 
+    if rank == 0:
+        write_metadata(p.file_id, ep, extra=[f"ranks, {world}", f"concurrent_per_rank, {a.concurrent}"])
     records = run_ensemble(p, ep, U_init=U_init, dist=dist, rank=rank, world=world, device=device,
                            concurrent=a.concurrent)
     if rank == 0:
         df, agg = write_results(p.file_id, records)
         print(agg.T)
         print('Output files:')
+        print(f"  {p.file_id}-metadata.csv")
         print(f"  {p.file_id}-results-agg.csv")
         print(f"  {p.file_id}-results.csv")
     if dist is not None:

@@ -12,6 +12,7 @@ class Solution:
         p = self.params = params
         self._U = None          # the field (solution.py:21); see the property U below
         self._U_fetch = None    # pending download of the device field
+        self._U_dirty = False   # a caller assigned U: the next solve_or_resume starts from it (solver.py:158)
         self.timedata = None
         # molar area [um^2/mol], solution.py:25
         self.Am = (25.13 * 1e6 / p.N_A) ** (2 / 3) * p.N_A
@@ -54,8 +55,17 @@ class Solution:
 
     @U.setter
     def U(self, value):
+        # a caller's field: `U = self.solution.U` (solver.py:158) is where every call of the reference
+        # starts, so the next solve_or_resume uploads it
         self.__dict__['_U_fetch'] = None
         self.__dict__['_U'] = value
+        self.__dict__['_U_dirty'] = value is not None
+
+    def _bind_device_U(self, host_copy=None, fetch=None):
+        """The engine's own field: `host_copy` mirrors it already, or `fetch()` downloads it on demand."""
+        self.__dict__['_U'] = host_copy
+        self.__dict__['_U_fetch'] = fetch
+        self.__dict__['_U_dirty'] = False
 
     def __getstate__(self):
         _ = self.U  # materialise a pending download: the engine does not travel

@@ -5,8 +5,12 @@ Same constructor, methods and result object as the reference class
 (``Solver(params, U_init)``, ``prepare()``, ``solve_or_resume(nsteps)`` ->
 ``Solution``), same quirks: the first ``solve_or_resume`` after ``prepare`` runs
 ``nsteps-1`` iterations (solver.py:160-165), ``hat_U`` is re-derived from ``U`` on
-every call (solver.py:159), ``prepare`` does not reset ``delt``/``time_delta_sum``/
-``skip_check`` (solver.py:50-54 are only set in ``__init__``).
+every call (solver.py:159), every call starts with the coefficient grids of
+``params.delt`` while ``self.delt`` keeps its adapted value until the adaptive
+step fires again (solver.py:154-155 against 185-193), ``prepare`` does not reset
+``delt``/``time_delta_sum``/``skip_check`` (solver.py:50-54 are only set in
+``__init__``), and a field assigned to ``solution.U`` between two calls is what the
+next call continues from (solver.py:158).
 """
 import numpy as np
 
@@ -130,7 +134,9 @@ class Solver:
             if fetch_U:
                 _ = self.solution.U
             else:
-                self.solution.U = self.solution.__dict__.get('_U')
+                # the caller needs scalars only: solution.U stays what the host already has (None when
+                # the field was never downloaded)
+                self.solution._bind_device_U(self.solution.__dict__.get('_U'))
             self._engine.close()
             self._engine = None
 
@@ -152,9 +158,8 @@ class Solver:
         row = eng.prepare()
         data = TimeData()
         data.insert(it=0, delt=row[8], E=row[1], E2=row[2], SA=0, domtime=0, Ra=row[5], L2=0, PS=row[7])
-        self.solution.U = U
-        if on_device:
-            self.solution._U_fetch = eng.get_U   # downloaded when somebody looks at solution.U
+        # on_device: downloaded when somebody looks at solution.U
+        self.solution._bind_device_U(U, eng.get_U if on_device else None)
         self.solution.timedata = data
         self.solution.tau0 = 0.0
         self.solution.t0 = 0.0
@@ -170,6 +175,10 @@ class Solver:
         if nsteps is None:
             nsteps = max(p.ntmax, 0)
         eng = self._engine
+        if self.solution.__dict__.get('_U_dirty'):
+            # the caller replaced the field since the last call: `U = self.solution.U` (solver.py:158)
+            eng.set_U(self.solution.U)
+            self.solution.__dict__['_U_dirty'] = False
         itbegin = 1 if self.solution.computed_steps == 1 else 0
         count = max(int(nsteps) - itbegin, 0)
 
@@ -203,8 +212,7 @@ class Solver:
                     break
             if count == 0:
                 self._pull_state()
-        self.solution.U = None
-        self.solution._U_fetch = eng.get_U   # downloaded when somebody looks at solution.U
+        self.solution._bind_device_U(None, eng.get_U)   # downloaded when somebody looks at solution.U
         return self.solution
 
     def _absorb(self, rows, rc, requested):
@@ -214,7 +222,7 @@ class Solver:
             if rows.shape[0] > 1:
                 sol.timedata.extend(rows[:-1])
             self._pull_state()
-            sol.U = self._engine.get_U()
+            sol._bind_device_U(self._engine.get_U())
             # the reference fails the same way: assert in TimeData.insert (timedata.py:10)
             raise AssertionError("NaN in a recorded scalar (U left (0,1)) at step %d" % sol.computed_steps)
         if rows.shape[0]:

@@ -73,6 +73,50 @@ def get_or_create_file_id(file_id):
     return file_id
 
 
+def vars_to_list(obj):
+    """Public non-callable attributes as ``name, value`` strings (``utils.py:213-223``)."""
+    out = []
+    for x in dir(obj):
+        if x.startswith('_') or not hasattr(obj, x):
+            continue
+        v = getattr(obj, x)
+        if callable(v):
+            continue
+        out.append(f"{x}, {v}")
+    return out
+
+
+def csv_export_list(fname, text):
+    """``utils.py:226-228``"""
+    with open(fname, 'w') as f:
+        f.writelines(text)
+
+
+def get_system_info():
+    """Host description for ``-metadata.csv`` (cf. ``utils.py:122-142``), plus the GPUs torch can see."""
+    import platform
+    import sys
+    from .version import __version__
+    uname = platform.uname()
+    info = [f"system, {uname.system}", f"nodename, {uname.node}", f"kernel-release, {uname.release}",
+            f"machine, {uname.machine}"]
+    try:
+        import psutil
+        info += [f"cores_phys, {psutil.cpu_count(logical=False)}", f"cores_total, {psutil.cpu_count(logical=True)}"]
+    except ImportError:  # pragma: no cover
+        import os
+        info += [f"cores_total, {os.cpu_count()}"]
+    try:
+        import torch
+        n = torch.cuda.device_count()
+        info += [f"gpus, {n}"]
+    except Exception:  # pragma: no cover
+        pass
+    info += [f"localtime, {datetime.now().strftime('%Y-%m-%d %H:%M:%S')}", f"argv, '{' '.join(sys.argv)}'",
+             f"chsimpy_amd-version, {__version__}"]
+    return info
+
+
 def get_int_max_value():
     return np.iinfo(np.intp).max
 

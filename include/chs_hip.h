@@ -93,8 +93,10 @@ typedef struct chs_handle_s* chs_handle;
  * lam_i = 2cos(pi i/(N-1)) - 2, i = 0..N-1 (chsimpy/utils.py:34-36); the N x N
  * grids CHeig/Seig of utils.py:39-49 are never materialised, they are formed on
  * the fly from this table and the current delt.
- * Environment (read here, test hook): CHS_ADAPT_SWEEP=1 keeps the separate sweep
- * of U for the adaptive-step column sums instead of the fused row kernel's. */
+ * Environment (read here, test hooks): CHS_ADAPT_SWEEP=1 keeps the separate sweep
+ * of U for the adaptive-step column sums instead of the fused row kernel's;
+ * CHS_BATCH_STEPS=n issues the steps of a call n at a time (default 1024) -- between
+ * batches the host looks at the device's stop flag, see chs_step_n. */
 int chs_create(const chs_consts* consts, const double* lambda, chs_handle* out);
 int chs_destroy(chs_handle h);
 
@@ -118,8 +120,11 @@ int chs_get_U(chs_handle h, double* host_U);
 int chs_prepare(chs_handle h, double row0[9]);
 
 /* Run up to `nsteps` iterations of solver.py:165-249 on the device without any
- * per-step host synchronisation.  On entry hat_U = dctn(U) is re-derived
- * (solver.py:159).  The caller passes the iteration count of
+ * per-step host synchronisation (the launches go out in batches; once the device
+ * has raised its stop flag no further batch is issued, so a run that stops early
+ * does not pay for the rest of ntmax).  On entry hat_U = dctn(U) is re-derived
+ * (solver.py:159) and the coefficients CHeig/Seig are those of consts.delt again
+ * (solver.py:154-155) until the adaptive step regenerates them (189-193).  The caller passes the iteration count of
  * range(itbegin, nsteps) (solver.py:160-165).  `rows` receives one 9-column
  * timedata row per completed step ([nsteps][9], column order timedata.py:9);
  * `*steps_done` how many were completed (fewer than nsteps after an energy or

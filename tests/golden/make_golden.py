@@ -5,6 +5,8 @@ which may neither be imported nor run: SURVEY.md section 8c).
 
 n64_lcg_40steps.npz : N=64, generator='lcg' (seed-portable, pinned by the reference's
                       LCG known-answer test), ntmax=40, full_sim, kappa_tilde explicit.
+n128_lcg_60steps.npz : the same generator at N=128, the smallest size of the fast transform engine
+                      (the reference-pinned LCG start field through the FFT-based kernels).
 n128_seed2023_200steps.npz : configs[0] of BASELINE.json (N=128, ntmax=200, seed 2023,
                       cinit 0.875): timedata + final U; its E/E2/min/max agree with the
                       reference observations recorded in SURVEY.md section 8(c).
@@ -30,6 +32,9 @@ def run(p):
 def main():
     s = run(orc.make_params(64, 40, generator='lcg', seed=2023))
     np.savez_compressed(os.path.join(HERE, 'n64_lcg_40steps.npz'), U_init=s.U_init, U_final=s.U,
+                        timedata=s.timedata.data())
+    s = run(orc.make_params(128, 60, generator='lcg', seed=2023))
+    np.savez_compressed(os.path.join(HERE, 'n128_lcg_60steps.npz'), U_init=s.U_init, U_final=s.U,
                         timedata=s.timedata.data())
     s = run(orc.make_params(128, 200))
     np.savez_compressed(os.path.join(HERE, 'n128_seed2023_200steps.npz'), U_final=s.U,

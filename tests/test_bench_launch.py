@@ -1,0 +1,34 @@
+"""CPU test of `python bench.py --gpus N` starting its own ranks (no torchrun around it): two gloo
+ranks through the same entry the driver uses, with `--dry-run` standing in for the device work."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, **env):
+    e = dict(os.environ, **env)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=e, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_starts_its_own_ranks_gloo_world2():
+    r = _run(['--gpus', '2', '--steps', '5', '--warmup', '1', '--dry-run'], CHS_DIST_BACKEND='gloo')
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                       # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 5
+    assert d['energies_last_step'] == [[0.0, 2.0], [1.0, 2.0]]   # all_gather: one record per rank, in rank order
+    assert 'dry-run' in d['data'] and d['value'] is None          # never mistaken for a measurement
+
+
+def test_bench_fails_when_a_rank_fails():
+    # the RCCL backend cannot come up without GPUs: every rank dies, the launcher must say so
+    r = _run(['--gpus', '2', '--steps', '5', '--dry-run'], CHS_DIST_BACKEND='nccl')
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]

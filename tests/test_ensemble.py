@@ -102,3 +102,70 @@ def _ctx():
     ep.runs = 4
     rv, al, _ = ex.make_rand_values(ep)
     return p, rv, al
+
+
+def test_metadata_csv(tmp_path):
+    """`<file_id>-metadata.csv` (experiment.py:193-195): system info, then the experiment parameters."""
+    ep = ex.ExperimentParams()
+    ep.runs, ep.A_source = 12, 'sobol'
+    fid = str(tmp_path / 'exp')
+    f = ex.write_metadata(fid, ep, extra=['ranks, 2'])
+    assert f == fid + '-metadata.csv'
+    lines = open(f).read().split('\n')
+    keys = [ln.split(',')[0] for ln in lines]
+    for k in ('system', 'nodename', 'cores_total', 'localtime', 'argv', 'ranks', 'A_seed', 'A_source', 'independent',
+              'jitter_Arelhigh', 'jitter_Arellow', 'processes', 'runs'):
+        assert k in keys, k
+    assert 'runs, 12' in lines and 'A_source, sobol' in lines and 'A_seed, 85972' in lines
+
+
+def test_file_A_source(tmp_path):
+    """`--A-source <file>` (experiment.py:189-190, 97-101): absolute (A0, A1) pairs from a CSV, no factors."""
+    A = np.array([[-151.0, -85.5], [-151.5, -85.75], [-150.25, -86.0]])
+    f = str(tmp_path / 'A.csv')
+    chsimpy_amd.utils.csv_export_matrix(A, f)
+    ep = ex.ExperimentParams()
+    ep.runs, ep.A_source = 5, f
+    rv, al, n = ex.make_rand_values(ep)
+    assert rv is None and n == 3 and np.array_equal(al, A)
+    p = chsimpy_amd.Parameters()
+    p.N, p.kappa_tilde, p.file_id = 16, 3e-4, 'ens'
+    recs = ex.run_ensemble(p, ep, run_fn=_fake_run)
+    assert len(recs) == 3
+    for i, rec in enumerate(recs):
+        assert rec[0] == A[i, 0] and rec[1] == A[i, 1] and rec[9] == i
+        assert np.isnan(rec[10]) and np.isnan(rec[11])
+    q, f0, f1 = ex.run_params(p, 1, rv, al)
+    assert f0 is None and f1 is None and q.file_id == 'ens-run1'
+    assert chsimpy_amd.Solution(q).A0 == A[1, 0] and chsimpy_amd.Solution(q).A1 == A[1, 1]
+
+
+def test_postprocessing_errors_are_raised_not_swallowed(monkeypatch, tmp_path):
+    """experiment.py:110-112: the thermodynamic post-processing is part of the run; when it fails the
+    run fails (no NaN columns slipping into the aggregate)."""
+    from chsimpy_amd import experiment, simulator
+
+    class _Sol:
+        A0, A1, tau0, t0 = -151.0, -85.0, 3, 0.5
+        E2 = np.array([1.0, 3.0, 2.0])
+
+    class _Sim:
+        def __init__(self, params, U_init=None):
+            self.solver = type('S', (), {'close': lambda self, fetch_U=True: None})()
+
+        def solve(self):
+            return _Sol()
+
+        def export(self):
+            return None
+
+    monkeypatch.setattr(simulator, 'Simulator', _Sim)
+    monkeypatch.setattr(experiment.utils, 'get_miscibility_gap', lambda *a, **k: (_ for _ in ()).throw(ValueError('no gap')))
+    p = chsimpy_amd.Parameters()
+    p.N, p.kappa_tilde, p.file_id = 16, 3e-4, str(tmp_path / 'e')
+    ep = ex.ExperimentParams()
+    rv, al, _ = ex.make_rand_values(ep)
+    with pytest.raises(ValueError):
+        ex.run_experiment_gpu(0, p, rv, al)
+    rec = ex.run_experiment_gpu(0, p, rv, al, postprocess=False)   # explicit opt-out: NaN columns
+    assert np.isnan(rec[2]) and rec[8] == 1 and rec[6] == 3

@@ -1,0 +1,215 @@
+"""GPU parity tests (``-m gpu``) of the run modes on the FAST transform engine (every N the benchmarks
+use): the reference's default mode -- the energy stop rule with ``full_sim=False`` (parameters.py:50,
+solver.py:242-251) --, the same rule with ``full_sim=True`` (deferred bookkeeping), ``adaptive_time``
+(solver.py:177-193) in one call and in chunks, and the batched issue of a long call.  Everything
+against ``OracleSolver`` on the same inputs.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import chsimpy_amd
+from oracle import chs_oracle as orc
+from gpu_helpers import KAPPA, RTOL, compare_run, make, relerr
+
+pytestmark = pytest.mark.gpu
+
+# (N, delt, step at which timedata.energy_falls first holds on the default start field; oracle runs)
+STOPS = [(128, 1e-6, 113), (256, 2.5e-7, 495)]
+
+
+@pytest.mark.parametrize("N,delt,stop", STOPS)
+def test_energy_stop_full_sim_false_fast_engine(gpu, N, delt, stop):
+    """full_sim=False on the fused pipeline: the tail runs in stream order, raises `halt` at the step
+    where E2[it-1] > E2[it] > E2[0] (timedata.py:63) and the field of that step is rebuilt from hat_U
+    (chs_fast_recover_u): same stop step, tau0, t0, stop_reason, U and record as the oracle."""
+    kw = dict(full_sim=False, delt=delt)
+    p = make(N, 6000, 'fast', **kw)
+    s = chsimpy_amd.Solver(p)
+    o = orc.OracleSolver(orc.make_params(N, 6000, **kw))
+    s.prepare(); o.prepare()
+    sol = s.solve_or_resume(); o.solve_or_resume()
+    assert s._engine.engine == 'fast'
+    assert sol.stop_reason == o.stop_reason == 'energy'
+    assert sol.computed_steps == o.computed_steps == stop and sol.tau0 == o.tau0 == stop
+    assert sol.t0 == pytest.approx(o.t0, rel=1e-12)
+    td, to = sol.timedata.data(), o.timedata.data()
+    assert td.shape == to.shape
+    assert np.allclose(td, to, rtol=1e-8, atol=1e-300), [relerr(td[:, c], to[:, c]) for c in range(1, 9)]
+    assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0), relerr(sol.U, o.U)
+    # resume after the stop (hat_U re-derived from the rebuilt U, solver.py:159)
+    for chunk in (1, 5, 30):
+        sol = s.solve_or_resume(chunk); o.solve_or_resume(chunk)
+        assert sol.computed_steps == o.computed_steps
+        assert sol.stop_reason == o.stop_reason and sol.tau0 == o.tau0
+        assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0), (chunk, relerr(sol.U, o.U))
+    td, to = sol.timedata.data(), o.timedata.data()
+    assert td.shape == to.shape and np.allclose(td, to, rtol=1e-8, atol=1e-300)
+    s.close()
+
+
+@pytest.mark.parametrize("N,delt,stop", STOPS)
+def test_energy_rule_full_sim_true_fast_engine(gpu, N, delt, stop):
+    """full_sim=True through the E2 maximum: the bookkeeping of step s rides in k_col of step s+1
+    (deferred tail) and must record tau0/t0 once and set skip_check (solver.py:242-249)."""
+    kw = dict(full_sim=True, delt=delt)
+    nt = stop + 40
+    sol, o = compare_run(make(N, nt, 'fast', **kw), kw, rtol=1e-8)
+    assert sol.stop_reason == 'None' and sol.computed_steps == nt
+    assert sol.tau0 == o.tau0 == stop
+    # ... and cut into calls around the maximum: skip_check survives the calls (solver.py:50,249)
+    s = chsimpy_amd.Solver(make(N, nt, 'fast', **kw))
+    o = orc.OracleSolver(orc.make_params(N, nt, **kw))
+    s.prepare(); o.prepare()
+    for chunk in (stop - 3, 2, 1, 1, 1, 38):
+        sol = s.solve_or_resume(chunk); o.solve_or_resume(chunk)
+        assert (sol.computed_steps, sol.tau0) == (o.computed_steps, o.tau0)
+        assert s.skip_check == o.skip_check
+    assert sol.t0 == pytest.approx(o.t0, rel=1e-12)
+    assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=1e-8, atol=1e-300)
+    assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0), relerr(sol.U, o.U)
+    s.close()
+
+
+@pytest.mark.parametrize("N", [128, 256])
+@pytest.mark.parametrize("chunks", [(600,), (300, 300), (300, 221, 7, 72)])
+def test_adaptive_time_fast_engine(gpu, N, chunks):
+    """adaptive_time on the fused pipeline (integrand column sums added up inside the row kernel,
+    k_colmin_rows, lam1/lam2 regenerated on the device) against the oracle: the delt history to 1e-9,
+    U/E/E2 to 1e-8 -- in one call and in chunks.  A chunk that starts beyond step 500 exercises the
+    reference's resume quirk: the call reloads the grids of params.delt (solver.py:154-155) while
+    self.delt keeps its adapted value until the next even step re-evaluates it (185-193).
+    delt_dyn is a column SUM (np.linalg.norm(.., ord=-1)) and grows with N: delt_max is scaled so that
+    the step settles at a few times params.delt instead of blowing up."""
+    kw = dict(adaptive_time=True, delt_max=4.9e-7 / N)
+    s = chsimpy_amd.Solver(make(N, 600, 'fast', **kw))
+    o = orc.OracleSolver(orc.make_params(N, 600, **kw))
+    s.prepare(); o.prepare()
+    for c in chunks:
+        sol = s.solve_or_resume(c); o.solve_or_resume(c)
+        assert sol.computed_steps == o.computed_steps
+    assert s._engine.engine == 'fast'
+    td, to = sol.timedata.data(), o.timedata.data()
+    assert td.shape == to.shape == (600, 9)
+    assert len(np.unique(to[:, 8])) > 20                         # the step really adapts
+    assert np.allclose(td[:, 8], to[:, 8], rtol=1e-9, atol=0), relerr(td[:, 8], to[:, 8])
+    for c in (1, 2, 4, 5, 6, 7):
+        assert np.allclose(td[:, c], to[:, c], rtol=1e-8, atol=1e-300), (c, relerr(td[:, c], to[:, c]))
+    assert np.array_equal(td[:, 3], to[:, 3])                    # SA: a count
+    assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0), relerr(sol.U, o.U)
+    assert s.delt == pytest.approx(o.delt, rel=1e-9) and s.time_passed == pytest.approx(o.time_passed, rel=1e-9)
+    s.close()
+
+
+def test_adaptive_resume_quirk_direct_engine(gpu):
+    """The same resume quirk on the direct engine (N=64, the reference's default delt_max)."""
+    kw = dict(adaptive_time=True)
+    s = chsimpy_amd.Solver(make(64, 600, 'direct', **kw))
+    o = orc.OracleSolver(orc.make_params(64, 600, **kw))
+    s.prepare(); o.prepare()
+    for c in (520, 1, 2, 77):
+        sol = s.solve_or_resume(c); o.solve_or_resume(c)
+    td, to = sol.timedata.data(), o.timedata.data()
+    assert np.allclose(td[:, 8], to[:, 8], rtol=1e-9, atol=0), relerr(td[:, 8], to[:, 8])
+    assert np.allclose(td[:, 1:3], to[:, 1:3], rtol=1e-8, atol=0)
+    assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0), relerr(sol.U, o.U)
+    s.close()
+
+
+@pytest.mark.parametrize("engine,N,delt,stop", [('fast', 128, 1e-6, 113), ('direct', 64, 3e-6, 72)])
+def test_batched_issue_stops_behind_the_halt_flag(gpu, engine, N, delt, stop, monkeypatch):
+    """chs_step_n issues its launches in batches and looks at the device's stop flag between them
+    (CHS_BATCH_STEPS, a test hook, makes the batches small): same rows, same field as one batch, and
+    the reference's defaults -- ntmax = 1e6, full_sim = False (parameters.py:42,50) -- return right
+    after the stop instead of queueing a million empty steps."""
+    runs = {}
+    for bs in ('7', None):
+        if bs:
+            monkeypatch.setenv('CHS_BATCH_STEPS', bs)
+        else:
+            monkeypatch.delenv('CHS_BATCH_STEPS', raising=False)
+        p = make(N, int(1e6), engine, full_sim=False, delt=delt)
+        s = chsimpy_amd.Solver(p)
+        s.prepare()
+        t0 = time.time()
+        sol = s.solve_or_resume()
+        dt = time.time() - t0
+        assert sol.stop_reason == 'energy' and sol.computed_steps == stop
+        assert dt < 5.0, dt
+        runs[bs] = (sol.U.copy(), sol.timedata.data().copy())
+        s.close()
+    assert np.array_equal(runs['7'][1], runs[None][1]) and np.array_equal(runs['7'][0], runs[None][0])
+    # a long full_sim call in small batches: the rows come out of the device ring batch by batch
+    monkeypatch.setenv('CHS_BATCH_STEPS', '16')
+    sol, o = compare_run(make(N, 150, engine), {})
+    assert sol.timedata.data().shape == (150, 9)
+
+
+def test_field_assigned_between_calls_is_picked_up(gpu):
+    """`U = self.solution.U` (solver.py:158): a caller that replaces solution.U between two calls
+    continues from that field."""
+    N = 128
+    s = chsimpy_amd.Solver(make(N, 0, 'fast'))
+    o = orc.OracleSolver(orc.make_params(N, 0))
+    s.prepare(); o.prepare()
+    sol = s.solve_or_resume(6); o.solve_or_resume(6)
+    V = np.clip(sol.U[::-1, :].copy() * 1.0001, 0.8, 0.95)
+    sol.U = V
+    o.U = V.copy()
+    sol = s.solve_or_resume(5); o.solve_or_resume(5)
+    assert np.allclose(sol.U, o.U, rtol=RTOL, atol=0), relerr(sol.U, o.U)
+    assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=RTOL, atol=1e-300)
+    s.close()
+
+
+def test_simulator_update_every_drives_chunks(gpu, tmp_path):
+    """Chunked driving (simulator.py:56-87): `update_every` steps per solve_or_resume, a host snapshot
+    handed to the view hook after every chunk, the last chunk shortened to hit ntmax, and the
+    tau0/t0 fix-up when the energy rule never fired (simulator.py:84-86)."""
+    N, nt, every = 128, 47, 10
+    seen = []
+    p = make(N, nt, 'fast')
+    p.update_every = every
+    p.file_id = str(tmp_path / 'chunks')
+    sim = chsimpy_amd.Simulator(p, on_update=lambda sm: seen.append((sm.solver.solution.computed_steps,
+                                                                     sm.solver.solution.U.copy())))
+    sol = sim.solve()
+    o = orc.OracleSolver(orc.make_params(N, nt))
+    o.prepare()
+    steps, snaps = [], []
+    left = nt
+    while left > 0:
+        c = min(every, left)
+        o.solve_or_resume(c)
+        steps.append(o.computed_steps); snaps.append(o.U.copy())
+        left -= c
+    assert [c for c, _ in seen] == steps
+    for (_, Ug), Uo in zip(seen, snaps):
+        assert np.allclose(Ug, Uo, rtol=RTOL, atol=0)
+    assert sim.steps_total == nt
+    assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=RTOL, atol=1e-300)
+    assert sol.tau0 == sol.computed_steps - 1 and sol.t0 == pytest.approx(o.time_passed, rel=1e-12)
+
+
+def test_uinit_file_import(gpu, tmp_path):
+    """`--Uinit-file` (simulator.py:21-22): the start field comes from a CSV written by
+    utils.csv_export_matrix (utils.py:79-83)."""
+    from chsimpy_amd import utils
+    N = 128
+    rng = np.random.default_rng(5)
+    U0 = 0.875 + 0.004 * (rng.random((N, N)) - 0.5)
+    f = str(tmp_path / 'u0.csv')
+    utils.csv_export_matrix(U0, f)
+    p = make(N, 12, 'fast')
+    p.Uinit_file = f
+    p.file_id = str(tmp_path / 'fromfile')
+    sim = chsimpy_amd.Simulator(p)
+    sol = sim.solve()
+    U0r = utils.csv_import_matrix(f)
+    o = orc.OracleSolver(orc.make_params(N, 12), U0r)
+    o.prepare(); o.solve_or_resume()
+    assert np.allclose(sol.U, o.U, rtol=RTOL, atol=0)
+    assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=RTOL, atol=1e-300)
+    sim.solver.close()

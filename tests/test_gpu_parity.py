@@ -14,54 +14,7 @@ from oracle import chs_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-KAPPA = 0.0002989112919661156
-RTOL = 1e-9
-GOLD = os.path.join(os.path.dirname(__file__), 'golden')
-
-
-def make(N, ntmax, engine='auto', **kw):
-    p = chsimpy_amd.Parameters()
-    p.N, p.ntmax, p.full_sim, p.kappa_tilde, p.engine = N, ntmax, True, KAPPA, engine
-    for k, v in kw.items():
-        setattr(p, k, v)
-    if 'threshold' not in kw:
-        p.threshold = p.XXX
-    return p
-
-
-def relerr(a, b):
-    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
-
-
-def _log_parity(p, engine, eu, cols):
-    d = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'gpurun_out')
-    if os.path.isdir(d):
-        with open(os.path.join(d, 'parity.log'), 'a') as f:
-            f.write(f"N={p.N} ntmax={p.ntmax} engine={engine} adaptive={p.adaptive_time} jitter={p.jitter} "
-                    f"delt={p.delt}: max rel err U={eu:.3e} E={cols[0]:.3e} E2={cols[1]:.3e} Ra={cols[2]:.3e} "
-                    f"L2={cols[3]:.3e} PS={cols[4]:.3e}\n")
-
-
-def compare_run(p, okw, U_init=None, rtol=RTOL, cols=(1, 2, 3, 4, 5, 6, 7, 8)):
-    s = chsimpy_amd.Solver(p, U_init)
-    s.prepare()
-    sol = s.solve_or_resume()
-    o = orc.OracleSolver(orc.make_params(p.N, p.ntmax, **okw), U_init)
-    o.prepare()
-    o.solve_or_resume()
-    td, to = sol.timedata.data(), o.timedata.data()
-    assert td.shape == to.shape
-    assert np.array_equal(td[:, 0], to[:, 0])
-    for c in cols:
-        assert np.allclose(td[:, c], to[:, c], rtol=rtol, atol=1e-300), (c, relerr(td[:, c], to[:, c]))
-    _log_parity(p, s._engine.engine, relerr(sol.U, o.U), [relerr(td[:, c], to[:, c]) for c in (1, 2, 5, 6, 7)])
-    assert np.allclose(sol.U, o.U, rtol=rtol, atol=0), relerr(sol.U, o.U)
-    assert sol.computed_steps == o.computed_steps
-    assert sol.stop_reason == o.stop_reason
-    assert sol.tau0 == o.tau0 and sol.t0 == pytest.approx(o.t0, rel=1e-12)
-    assert s.time_passed == pytest.approx(o.time_passed, rel=1e-12)
-    s.close()
-    return sol, o
+from gpu_helpers import GOLD, KAPPA, RTOL, compare_run, make, relerr  # noqa: F401
 
 
 @pytest.mark.parametrize("engine,N", [('direct', 64), ('direct', 100), ('direct', 128), ('fast', 128), ('fast', 256),
@@ -103,16 +56,17 @@ def test_config0_n128_200steps_vs_oracle_and_golden(gpu, engine):
     assert sol.E2[-1] == pytest.approx(8.73563379288026e-18, rel=1e-9)
 
 
-@pytest.mark.parametrize("engine", ['direct', 'fast'])
-def test_golden_lcg_fixture(gpu, engine):
-    g = np.load(os.path.join(GOLD, 'n64_lcg_40steps.npz'))
-    if engine == 'fast':
-        pytest.skip("fast engine starts at N=128")
-    p = make(64, 40, engine, generator='lcg')
+@pytest.mark.parametrize("engine,N,nt", [('direct', 64, 40), ('direct', 128, 60), ('fast', 128, 60)])
+def test_golden_lcg_fixture(gpu, engine, N, nt):
+    """The reference-pinned start field (`generator='lcg'`, solver.py:66, known-answer test
+    tests/test.py:25-37) through both transform engines against the committed fixtures."""
+    g = np.load(os.path.join(GOLD, f'n{N}_lcg_{nt}steps.npz'))
+    p = make(N, nt, engine, generator='lcg')
     s = chsimpy_amd.Solver(p)
     assert np.array_equal(s.U_init, g['U_init'])
     s.prepare()
     sol = s.solve_or_resume()
+    assert s._engine.engine == engine
     assert np.allclose(sol.timedata.data(), g['timedata'], rtol=RTOL, atol=1e-300)
     assert np.allclose(sol.U, g['U_final'], rtol=RTOL, atol=0)
     s.close()
