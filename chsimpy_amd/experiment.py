@@ -16,11 +16,17 @@ results do not depend on how many ranks share the work.
 """
 import argparse
 import os
+import threading
 
 import numpy as np
 
 from . import utils
 from .parameters import Parameters
+
+# sympy/mpmath keep their working precision in a process-global context (nsolve(prec=7) switches it
+# temporarily): concurrent members of one rank take turns in the thermodynamic post-processing.  (The
+# reference runs its members in separate processes, experiment.py:211.)
+_SYMPY_LOCK = threading.Lock()
 
 COLS = ['A0', 'A1', 'ca', 'cb', 'sa', 'sb', 'tau0', 't0', 'tsep', 'id', 'fac_A0', 'fac_A1']  # experiment.py:218
 
@@ -115,9 +121,10 @@ def run_experiment_gpu(run_id, init_params, rand_values, A_list, U_init=None, po
         # experiment.py:110-112 -- a failure here (sympy missing, no common tangent, not exactly two
         # spinodal roots) is an error of the run, as in the reference: a silent NaN would poison
         # -results-agg.csv.  postprocess=False skips the thermodynamic columns explicitly.
-        cgap = utils.get_miscibility_gap(params.R, params.temp, params.B, solution.A0, solution.A1)
-        ca, cb = float(cgap[0]), float(cgap[1])
-        sa, sb = (float(r) for r in utils.get_roots_of_EPP(params.R, params.temp, solution.A0, solution.A1))
+        with _SYMPY_LOCK:
+            cgap = utils.get_miscibility_gap(params.R, params.temp, params.B, solution.A0, solution.A1)
+            ca, cb = float(cgap[0]), float(cgap[1])
+            sa, sb = (float(r) for r in utils.get_roots_of_EPP(params.R, params.temp, solution.A0, solution.A1))
     itargmax = int(np.argmax(solution.E2))
     simulator.solver.close(fetch_U=False)   # the record needs scalars only
     return (solution.A0, solution.A1, ca, cb, sa, sb, solution.tau0, solution.t0, itargmax, run_id,

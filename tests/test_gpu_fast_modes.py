@@ -17,7 +17,25 @@ from gpu_helpers import KAPPA, RTOL, compare_run, make, relerr
 pytestmark = pytest.mark.gpu
 
 # (N, delt, step at which timedata.energy_falls first holds on the default start field; oracle runs)
-STOPS = [(128, 1e-6, 113), (256, 2.5e-7, 495)]
+STOPS = [(128, 1e-6, 113), (256, 1.8e-7, 682)]
+
+# These runs go through the whole spinodal growth up to the E2 maximum with a large time step: round-off
+# differences between two correct transform implementations grow with the unstable modes, hence rtol 1e-8
+# (as in the N=64 energy-stop tests) instead of the 1e-9 of the plain runs.  L2 = ||mu||_F / N^2
+# (solver.py:225) is worse conditioned than U itself: mu ~ 0.24 is the sum of terms of size ~100
+# (RT ln(U/(1-U)) - BRT + ...), so a relative error eps in U shows up as ~400 eps in L2.
+# Conditioning of the chosen runs, measured on the oracle itself (one-ulp perturbation of U_init -> change
+# of the final U): N=128/delt=1e-6: 1.2e-9, N=256/delt=1.8e-7: 4.5e-10 (N=256/delt=2.5e-7 would be
+# 4e-7: too close to the stability limit of the explicit nonlinear term to compare two codes at 1e-8).
+RTOL_LONG = 1e-8
+RTOL_LONG_L2 = 400 * RTOL_LONG
+
+
+def close_long(td, to):
+    assert td.shape == to.shape
+    errs = [relerr(td[:, c], to[:, c]) for c in range(9)]
+    for c in range(9):
+        assert errs[c] <= (RTOL_LONG_L2 if c == 6 else RTOL_LONG), (c, errs)
 
 
 @pytest.mark.parametrize("N,delt,stop", STOPS)
@@ -35,18 +53,15 @@ def test_energy_stop_full_sim_false_fast_engine(gpu, N, delt, stop):
     assert sol.stop_reason == o.stop_reason == 'energy'
     assert sol.computed_steps == o.computed_steps == stop and sol.tau0 == o.tau0 == stop
     assert sol.t0 == pytest.approx(o.t0, rel=1e-12)
-    td, to = sol.timedata.data(), o.timedata.data()
-    assert td.shape == to.shape
-    assert np.allclose(td, to, rtol=1e-8, atol=1e-300), [relerr(td[:, c], to[:, c]) for c in range(1, 9)]
-    assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0), relerr(sol.U, o.U)
+    close_long(sol.timedata.data(), o.timedata.data())
+    assert np.allclose(sol.U, o.U, rtol=RTOL_LONG, atol=0), relerr(sol.U, o.U)
     # resume after the stop (hat_U re-derived from the rebuilt U, solver.py:159)
     for chunk in (1, 5, 30):
         sol = s.solve_or_resume(chunk); o.solve_or_resume(chunk)
         assert sol.computed_steps == o.computed_steps
         assert sol.stop_reason == o.stop_reason and sol.tau0 == o.tau0
         assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0), (chunk, relerr(sol.U, o.U))
-    td, to = sol.timedata.data(), o.timedata.data()
-    assert td.shape == to.shape and np.allclose(td, to, rtol=1e-8, atol=1e-300)
+    close_long(sol.timedata.data(), o.timedata.data())
     s.close()
 
 
@@ -56,9 +71,16 @@ def test_energy_rule_full_sim_true_fast_engine(gpu, N, delt, stop):
     (deferred tail) and must record tau0/t0 once and set skip_check (solver.py:242-249)."""
     kw = dict(full_sim=True, delt=delt)
     nt = stop + 40
-    sol, o = compare_run(make(N, nt, 'fast', **kw), kw, rtol=1e-8)
-    assert sol.stop_reason == 'None' and sol.computed_steps == nt
-    assert sol.tau0 == o.tau0 == stop
+    s = chsimpy_amd.Solver(make(N, nt, 'fast', **kw))
+    o = orc.OracleSolver(orc.make_params(N, nt, **kw))
+    s.prepare(); o.prepare()
+    sol = s.solve_or_resume(); o.solve_or_resume()
+    assert sol.stop_reason == o.stop_reason == 'None' and sol.computed_steps == o.computed_steps == nt
+    assert sol.tau0 == o.tau0 == stop and sol.t0 == pytest.approx(o.t0, rel=1e-12)
+    assert s.skip_check and o.skip_check
+    close_long(sol.timedata.data(), o.timedata.data())
+    assert np.allclose(sol.U, o.U, rtol=RTOL_LONG, atol=0), relerr(sol.U, o.U)
+    s.close()
     # ... and cut into calls around the maximum: skip_check survives the calls (solver.py:50,249)
     s = chsimpy_amd.Solver(make(N, nt, 'fast', **kw))
     o = orc.OracleSolver(orc.make_params(N, nt, **kw))
@@ -68,8 +90,8 @@ def test_energy_rule_full_sim_true_fast_engine(gpu, N, delt, stop):
         assert (sol.computed_steps, sol.tau0) == (o.computed_steps, o.tau0)
         assert s.skip_check == o.skip_check
     assert sol.t0 == pytest.approx(o.t0, rel=1e-12)
-    assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=1e-8, atol=1e-300)
-    assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0), relerr(sol.U, o.U)
+    close_long(sol.timedata.data(), o.timedata.data())
+    assert np.allclose(sol.U, o.U, rtol=RTOL_LONG, atol=0), relerr(sol.U, o.U)
     s.close()
 
 
