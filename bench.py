@@ -220,7 +220,8 @@ def main():
     if prewarm:
         eng.step_n(prewarm)
     rows_w, rc_w = eng.step_n(a.warmup)
-    assert rc_w == 0 and rows_w.shape[0] == a.warmup
+    nocheck = os.environ.get('CHS_BENCH_NOCHECK') == '1'  # timing experiments with deliberately wrong kernels (tools/ab.sh)
+    assert nocheck or (rc_w == 0 and rows_w.shape[0] == a.warmup)
     # keep the input resident: nothing is uploaded inside the timed region; the
     # entry transform hat_U = dctn(U) of solve_or_resume (solver.py:159) is part of it.
     sync()
@@ -228,7 +229,7 @@ def main():
     rows, rc = eng.step_n(a.steps)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    assert rows.shape[0] == a.steps and rc == 0, (rows.shape, rc)
+    assert nocheck or (rows.shape[0] == a.steps and rc == 0), (rows.shape, rc)
     dt = t1 - t0
     dev_ms = eng.last_step_ms()
     if dist is not None:

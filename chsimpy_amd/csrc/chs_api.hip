@@ -331,15 +331,23 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   E->timer.on = false;  // the entry work is not a per-step kernel
   // a new call re-arms the loop and reloads the coefficients of params.delt (k_call_begin)
   if ((rc = chs_launch_call_begin(E))) return rc;
-  if (!((flags & CHS_STEP_CARRY_HAT) && E->hat_valid)) {
-    if ((rc = enter(E))) return rc;
-  }
-  E->hat_valid = true;
-  E->timer.on = profile;
   const bool fused = (E->engine == CHS_ENGINE_FAST) && !((E->dNoise || E->jitterPcg) && E->jitter > 0.0 && E->jitter < 0.1);
-  if (fused && nsteps > 0) {
-    if ((rc = chs_fast_prologue(E))) { E->timer.on = false; return rc; }
+  const bool derive = !((flags & CHS_STEP_CARRY_HAT) && E->hat_valid);
+  if (derive && fused && nsteps > 0) {
+    // hat_U = dctn(U) and the first step's row transform of EnergieEut(U) from one sweep of U
+    if ((rc = chs_fast_enter_fused(E))) return rc;
+    E->hat_valid = true;
+  } else {
+    if (derive) {
+      if ((rc = enter(E))) return rc;
+    }
+    E->hat_valid = true;
+    E->timer.on = profile;
+    if (fused && nsteps > 0) {
+      if ((rc = chs_fast_prologue(E))) { E->timer.on = false; return rc; }
+    }
   }
+  E->timer.on = profile;
   int64_t issued = 0, copied = 0;
   int batch = 0;
   bool stopped = false;

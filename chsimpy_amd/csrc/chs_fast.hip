@@ -65,6 +65,21 @@ template <class C>
 __device__ __forceinline__ size_t tile_addr(int r, int k) {
   return ((size_t)(k / C::CT) * C::N + r) * C::CT + (k % C::CT);
 }
+// Element (r, k) of a tile-major array through a 32-bit BYTE offset from the (uniform) array base: the
+// access becomes `global_load/store v, voffset, s[base]` -- one or two integer instructions per address
+// instead of a 64-bit multiply-add chain.  N*N*sizeof(T) < 2^32 for every configuration (<= 512 MB).
+template <class C>
+__device__ __forceinline__ unsigned tile_boff(unsigned r, unsigned k) {
+  return (((k / C::CT) * C::N + r) * C::CT + (k % C::CT)) * (unsigned)sizeof(typename C::T);
+}
+template <typename T>
+__device__ __forceinline__ const T* at_boff(const T* base, unsigned boff) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
+}
+template <typename T>
+__device__ __forceinline__ T* at_boff(T* base, unsigned boff) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff);
+}
 
 // First row of a row-kernel workgroup.  CT consecutive rows share 128-byte lines of T1/T2; when
 // a workgroup holds fewer rows (C < CT) the CT/C workgroups of one line group are given block
@@ -180,6 +195,9 @@ __device__ __forceinline__ void stagger_start() {
 // offsets is far cheaper than holding dozens of address registers across a phase.
 __device__ __forceinline__ int launder(int x) {
   asm volatile("" : "+v"(x));
+  // lane / thread indices only: without the range the divisions and remainders by powers of two that
+  // the index maps are made of compile to signed sequences (4-5 instructions instead of one shift)
+  __builtin_assume(x >= 0 && x < 1024);
   return x;
 }
 
@@ -208,15 +226,15 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
   T re[C::E], im[C::E];
   double s2 = 0.0;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
-  const T* urow = U + (size_t)row * C::N;
+  const unsigned urow = (unsigned)row * C::N;  // (32-bit offsets from the uniform base, see tile_boff)
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
     const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
 #pragma unroll
     for (int j = 0; j < C::R0 / 2; ++j) {
       T q1[4], q2[4];
-      load4<T>(urow + 4 * (size_t)(m1 + C::L1 * j), q1);
-      load4<T>(urow + 4 * (size_t)(m2 + C::L1 * j), q2);
+      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
       pack_quads<C>(q1, q2, q, j, re, im);
     }
   }
@@ -233,13 +251,70 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
                             [&](int, const int idx[4], T y[4], bool live, NoFetch) {
     if (live) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
+      for (int t = 0; t < 4; ++t) *at_boff(T1, tile_boff<C>(row, idx[t])) = y[t];
     }
   }, [](int, const int*, T*, bool) {});
   if constexpr (POINTWISE) {
     const double tot = block_sum(s2, red);
     if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
   }
+}
+
+// ---------------------------------------------------------------------------
+// k_row_fwd2: the entry of a solve_or_resume call on the fused pipeline in ONE sweep of U:
+//   Ta <- row DCT-II of U            (the row half of hat_U = dctn(U), solver.py:159)
+//   T1 <- row DCT-II of EnergieEut(U) (what the fused row kernel of a previous step would have left)
+// and the block's sum(mu^2) (solver.py:225).  U is read once; both operands live in registers
+// (compiled for two waves per SIMD: no spills), the two transforms run one after the other.
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(C::THREADS, 2) void k_row_fwd2(const typename C::T* __restrict__ U, typename C::T* __restrict__ Ta,
+                                                            typename C::T* __restrict__ T1, FTables<typename C::T> tb,
+                                                            DevConsts dc, const DevState* __restrict__ st,
+                                                            double* __restrict__ partMu) {
+  using T = typename C::T;
+  __shared__ double red[32];
+  if (st->halt) return;
+  T* lds = reinterpret_cast<T*>(chs_dyn_lds);
+  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
+  const int row = row_of_block<C>(blockIdx.x) + sub;
+  T* scr = lds + (size_t)sub * C::SCR;
+  T re[C::E], im[C::E], mre[C::E], mim[C::E];
+  double s2 = 0.0;
+  const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
+  const unsigned urow = (unsigned)row * C::N;
+#pragma unroll
+  for (int q = 0; q < C::NP0; ++q) {
+    const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+    for (int j = 0; j < C::R0 / 2; ++j) {
+      T q1[4], q2[4];
+      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+      pack_quads<C>(q1, q2, q, j, re, im);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < C::E; ++e) {
+    mre[e] = chs_mu<T>(re[e], RT, BRT, A0, A1);
+    mim[e] = chs_mu<T>(im[e], RT, BRT, A0, A1);
+    s2 += (double)mre[e] * (double)mre[e] + (double)mim[e] * (double)mim[e];
+  }
+  auto transform = [&](T* a, T* b, T* dst) {
+    fwd_passes<C>(a, b, scr, tb, launder(l));
+    recombine<C, true, false, false>(a, b, tb, launder(l), [](int, const int*) { return NoFetch{}; },
+                              [&](int, const int idx[4], T y[4], bool live, NoFetch) {
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *at_boff(dst, tile_boff<C>(row, idx[t])) = y[t];
+      }
+    }, [](int, const int*, T*, bool) {});
+  };
+  transform(re, im, Ta);
+  __builtin_amdgcn_sched_barrier(0);
+  transform(mre, mim, T1);
+  const double tot = block_sum(s2, red);
+  if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
 }
 
 // ---------------------------------------------------------------------------
@@ -298,13 +373,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   recombine<C, false, true, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
                             [&](int, const int idx[4], T y[4], bool, NoFetch) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) y[t] = T2[tile_addr<C>(row, idx[t])];
+    for (int t = 0; t < 4; ++t) y[t] = *at_boff(T2, tile_boff<C>(row, idx[t]));
   }, [](int, const int*, T*, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
   inv_passes<C>(re, im, scr, tbp, launder(l));
   if constexpr (DIAG && FUSE) STAMP(0, 2);
   __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
-  T* urow = U + (size_t)row * C::N;
+  const unsigned urow = (unsigned)row * C::N;
   double sEdge = 0.0;
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int ls = launder(l);
@@ -320,8 +395,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       for (int j = 0; j < C::R0 / 2; ++j) {
         T q1[4], q2[4];
         unpack_quads<C>(re, im, q, j, q1, q2);
-        store4<T>(urow + 4 * (size_t)(m1 + C::L1 * j), q1);
-        store4<T>(urow + 4 * (size_t)(m2 + C::L1 * j), q2);
+        store4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+        store4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
       }
     }
   }
@@ -372,8 +447,12 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       const T uinv = T(1) - u;
       bad |= ((u > T(0)) && (uinv > T(0))) ? 0 : 1;
       T lU, lV;
+#ifdef CHS_DIAG_NOLOG  // timing experiment only (wrong results): what the two logarithms cost
+      lU = u; lV = uinv;
+#else
       if constexpr (CHS_LOG_TABLE) { lU = chs_log_pos_tab<T>(u, ltab); lV = chs_log_pos_tab<T>(uinv, ltab); }
       else { lU = chs_log_pos<T>(u); lV = chs_log_pos<T>(uinv); }
+#endif
       sE += (double)chs_energy_from_logs_fast<T>(u, uinv, lU, lV, RT, B, A0, A1);
       sPS += fabs((double)u - mean);
       cSA += ((double)u < thr) ? 1.0 : 0.0;
@@ -458,7 +537,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
                               [&](int, const int idx[4], T y[4], bool live) {
       if (live) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) T1[tile_addr<C>(row, idx[t])] = y[t];
+        for (int t = 0; t < 4; ++t) *at_boff(T1, tile_boff<C>(row, idx[t])) = y[t];
       }
     });
   }
@@ -819,6 +898,7 @@ struct FastPlan {
   void* tables = nullptr;  // one device allocation
   size_t off_tw0, off_twa, off_twb, off_wp, off_t1, off_t2;  // element offsets
   int (*row_fwd)(Engine*, const void*, void*, bool) = nullptr;
+  int (*row_fwd2)(Engine*, const void*, void*, void*) = nullptr;
   int (*row_inv)(Engine*, int, const void*, void*, void*) = nullptr;
   int (*col)(Engine*, int, const void*, void*, void*, void*) = nullptr;
   int (*init)(Engine*) = nullptr;
@@ -856,6 +936,7 @@ struct Launch {
     int rc;
     if ((rc = set_lds(k_row_fwd<C, true>, row_lds))) return rc;
     if ((rc = set_lds(k_row_fwd<C, false>, row_lds))) return rc;
+    if ((rc = set_lds(k_row_fwd2<C>, row_lds))) return rc;
     if ((rc = set_lds(k_row_inv<C, false, false>, row_lds))) return rc;
     if ((rc = set_lds(k_row_inv<C, true, false>, row_lds))) return rc;
     if ((rc = set_lds(k_row_inv<C, true, true>, row_lds))) return rc;
@@ -878,6 +959,12 @@ struct Launch {
     else
       k_row_fwd<C, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
                                                              E->dPartMu);
+    CHS_HIP(hipGetLastError());
+    return CHS_OK;
+  }
+  static int row_fwd2(Engine* E, const void* in, void* ta, void* t1) {
+    k_row_fwd2<C><<<C::N / C::C, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)ta, (T*)t1, get_tables<T>(E), E->dc,
+                                                                E->dState, E->dPartMu);
     CHS_HIP(hipGetLastError());
     return CHS_OK;
   }
@@ -990,6 +1077,7 @@ static void bind(FastPlan* P) {
   P->N = C::N; P->G = C::G; P->R0 = C::R0; P->RA = C::RA; P->RB = C::RB; P->RL = C::RL; P->threads = C::THREADS;
   P->col_tiles = CC::N / CC::C;
   P->row_fwd = &Launch<C, CC>::row_fwd;
+  P->row_fwd2 = &Launch<C, CC>::row_fwd2;
   P->row_inv = &Launch<C, CC>::row_inv;
   P->col = &Launch<C, CC>::col;
   P->init = &Launch<C, CC>::init;
@@ -1161,6 +1249,20 @@ static void select_partial_set(Engine* E) {
   const int par = E->parity;
   E->dPartDiag = E->partSet[par][0]; E->dPartMu = E->partSet[par][1];
   E->dPartE2 = E->partSet[par][2]; E->dPartRa = E->partSet[par][3];
+}
+
+// Entry of a call on the fused pipeline: hat_U <- dctn(U) (solver.py:159) and the prologue below with
+// one sweep of U instead of two (k_row_fwd2), the row transform of U parked in the idle T2 buffer.
+int chs_fast_enter_fused(Engine* E) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  E->tailDeferred = false;
+  select_partial_set(E);
+  int rc;
+  chs_slot_begin(E, SLOT_MU);
+  rc = P->row_fwd2(E, E->dU, E->dT2, E->dT1);
+  chs_slot_end(E, SLOT_MU);
+  if (rc) return rc;
+  return P->col(E, MODE_FWD_NATIVE, E->dT2, nullptr, E->dHat, nullptr);
 }
 
 int chs_fast_prologue(Engine* E) {

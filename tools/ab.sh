@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 for r in $(seq $rounds); do
   for v in chsimpy_amd/lib/variants/*.so; do
     cp $v chsimpy_amd/lib/libchs_hip.so
-    timeout -k 10 200 python bench.py --no-cpu-baseline $args > gpurun_out/ab_one.log 2>&1 || { echo "$v failed"; tail -5 gpurun_out/ab_one.log; exit 1; }
+    timeout -k 10 200 python bench.py --no-cpu-baseline $args > gpurun_out/ab_one.log 2>&1 || { echo "$v failed"; tail -3 gpurun_out/ab_one.log; continue; }
     python - "$v" <<'PY' | tee -a gpurun_out/ab.log
 import json, sys
 d = json.loads(open('gpurun_out/ab_one.log').read().strip().splitlines()[-1])
