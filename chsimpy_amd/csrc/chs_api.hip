@@ -57,6 +57,7 @@ static void timer_harvest(Engine* E) {
 }
 
 // ---------------------------------------------------------------------------
+#define CHS_ROWS_STAGED 4096  // rows of the pinned staging buffer for short calls (run_steps)
 #define CHS_ROWS_RING 65536  // rows of the device ring (4.7 MB), a multiple of the batch size of run_steps
 
 // timedata rows of the running call: one allocation for the handle's lifetime, used as a ring (run_steps)
@@ -80,6 +81,7 @@ static void free_engine(Engine* E) {
   if (E->evB) hipEventDestroy(E->evB);
   for (int i = 0; i < 4; ++i) if (E->evPoll[i]) hipEventDestroy(E->evPoll[i]);
   if (E->hState) hipHostFree(E->hState);
+  if (E->hRows) hipHostFree(E->hRows);
   if (E->stream) hipStreamDestroy(E->stream);
   delete E;
 }
@@ -130,6 +132,7 @@ extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle*
   TRY_HIP(hipEventCreate(&E->evB));
   for (int i = 0; i < 4; ++i) TRY_HIP(hipEventCreateWithFlags(&E->evPoll[i], hipEventDisableTiming));
   TRY_HIP(hipHostMalloc((void**)&E->hState, sizeof(DevState) * 5, hipHostMallocDefault));
+  TRY_HIP(hipHostMalloc((void**)&E->hRows, sizeof(double) * 9 * CHS_ROWS_STAGED, hipHostMallocDefault));
   const size_t nb = (size_t)N * N * E->esz;
   TRY_HIP(hipMalloc(&E->dU, nb));
   TRY_HIP(hipMalloc(&E->dMU, nb));
@@ -379,6 +382,9 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   if (profile) { timer_harvest(E); E->timer.on = false; }
   CHS_HIP(hipEventRecord(E->evB, E->stream));
   CHS_HIP(hipMemcpyAsync(&E->hState[0], E->dState, sizeof(DevState), hipMemcpyDeviceToHost, E->stream));
+  // a short call fetches its rows in the same breath (pinned staging): one wait for state and record
+  const bool staged = rows && copied == 0 && nsteps > 0 && nsteps <= CHS_ROWS_STAGED;
+  if (staged) CHS_HIP(hipMemcpyAsync(E->hRows, E->dRows, sizeof(double) * 9 * (size_t)nsteps, hipMemcpyDeviceToHost, E->stream));
   CHS_HIP(hipStreamSynchronize(E->stream));
   float ms = 0.f;
   CHS_HIP(hipEventElapsedTime(&ms, E->evA, E->evB));
@@ -399,7 +405,9 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   int64_t done = s.rows_written;
   if (done > nsteps) done = nsteps;
   if (steps_done) *steps_done = done;
-  if (rows && done > copied) {
+  if (staged) {
+    memcpy(rows, E->hRows, sizeof(double) * 9 * (size_t)done);
+  } else if (rows && done > copied) {
     if ((rc = copy_rows_out(E, rows, copied, done))) return rc;
   }
   if (rows) {

@@ -176,6 +176,7 @@ struct Engine {
   double* partSet[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // Diag, Mu, E2, Ra
   int parity = 0;
   bool tailDeferred = false;  // the tail of the previous step is still to run
+  bool preRider = false;      // the first step's time-step control rides in its k_col (deferred-tail mode)
   unsigned stepCount = 0;     // k_col<MODE_STEP> launches so far (tile walk direction alternates)
   // jitter noise generated on the device: numpy's PCG64 stream continued from the host generator's state
   bool jitterPcg = false;
@@ -188,6 +189,7 @@ struct Engine {
   // pinned host mirror of the device state: slot 0 = the state at the end of a call, slots 1..4 = the
   // polls behind the batches of a long call (run_steps)
   DevState* hState = nullptr;
+  double* hRows = nullptr;    // pinned staging of the rows of a short call
   hipEvent_t evPoll[4] = {nullptr, nullptr, nullptr, nullptr};
   int batchSteps = 1024;      // steps issued between two looks at the device's halt flag (run_steps)
   double lastStepMs = 0.0;

@@ -261,17 +261,19 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
 }
 
 // ---------------------------------------------------------------------------
-// k_row_fwd2: the entry of a solve_or_resume call on the fused pipeline in ONE sweep of U:
+// k_row_fwd2: the entry of a solve_or_resume call on the fused pipeline in ONE launch:
 //   Ta <- row DCT-II of U            (the row half of hat_U = dctn(U), solver.py:159)
 //   T1 <- row DCT-II of EnergieEut(U) (what the fused row kernel of a previous step would have left)
-// and the block's sum(mu^2) (solver.py:225).  U is read once; both operands live in registers
-// (compiled for two waves per SIMD: no spills), the two transforms run one after the other.
+// and the block's sum(mu^2) (solver.py:225).  The two transforms run one after the other on the same
+// registers (four waves per SIMD like the other row kernels); the second pass re-reads the row of U
+// the workgroup has just read (L2), so HBM sees U once.  EnergieEut uses the shared-log form of the
+// fused row kernel (log U - log(1-U) from the table-driven log).
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(C::THREADS, 2) void k_row_fwd2(const typename C::T* __restrict__ U, typename C::T* __restrict__ Ta,
-                                                            typename C::T* __restrict__ T1, FTables<typename C::T> tb,
-                                                            DevConsts dc, const DevState* __restrict__ st,
-                                                            double* __restrict__ partMu) {
+__global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename C::T* __restrict__ U, typename C::T* __restrict__ Ta,
+                                                                 typename C::T* __restrict__ T1, FTables<typename C::T> tb,
+                                                                 DevConsts dc, const DevState* __restrict__ st,
+                                                                 double* __restrict__ partMu) {
   using T = typename C::T;
   __shared__ double red[32];
   if (st->halt) return;
@@ -279,40 +281,59 @@ __global__ __launch_bounds__(C::THREADS, 2) void k_row_fwd2(const typename C::T*
   const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
   const int row = row_of_block<C>(blockIdx.x) + sub;
   T* scr = lds + (size_t)sub * C::SCR;
-  T re[C::E], im[C::E], mre[C::E], mim[C::E];
+  double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
+  if constexpr (CHS_LOG_TABLE && sizeof(T) == 8) {
+    for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
+    __syncthreads();
+  }
+  T re[C::E], im[C::E];
   double s2 = 0.0;
+  unsigned dom = 0;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
-  const unsigned urow = (unsigned)row * C::N;
 #pragma unroll
-  for (int q = 0; q < C::NP0; ++q) {
-    const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int lp = launder(l);
+    const unsigned urow = (unsigned)launder(row) * C::N;
 #pragma unroll
-    for (int j = 0; j < C::R0 / 2; ++j) {
-      T q1[4], q2[4];
-      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
-      pack_quads<C>(q1, q2, q, j, re, im);
+    for (int q = 0; q < C::NP0; ++q) {
+      const int m1 = lp + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+      for (int j = 0; j < C::R0 / 2; ++j) {
+        T q1[4], q2[4];
+        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+        pack_quads<C>(q1, q2, q, j, re, im);
+      }
     }
-  }
+    if (pass == 1) {
+      auto mu = [&](T& u) {
+        const T uinv = T(1) - u;
+        T m;
+        if constexpr (CHS_LOG_TABLE) {
+          const T lU = chs_log_unit_tab<T>(u, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
+          m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
+        } else {
+          m = chs_mu<T>(u, RT, BRT, A0, A1);
+        }
+        s2 += (double)m * (double)m;
+        u = m;
+        asm volatile("" : "+v"(u), "+v"(s2), "+v"(dom));  // one grid point at a time (register pressure)
+      };
 #pragma unroll
-  for (int e = 0; e < C::E; ++e) {
-    mre[e] = chs_mu<T>(re[e], RT, BRT, A0, A1);
-    mim[e] = chs_mu<T>(im[e], RT, BRT, A0, A1);
-    s2 += (double)mre[e] * (double)mre[e] + (double)mim[e] * (double)mim[e];
-  }
-  auto transform = [&](T* a, T* b, T* dst) {
-    fwd_passes<C>(a, b, scr, tb, launder(l));
-    recombine<C, true, false, false>(a, b, tb, launder(l), [](int, const int*) { return NoFetch{}; },
+      for (int e = 0; e < C::E; ++e) { mu(re[e]); mu(im[e]); }
+      if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of the first step becomes NaN
+    }
+    T* dst = pass ? T1 : Ta;
+    fwd_passes<C>(re, im, scr, tb, launder(l));
+    recombine<C, true, false, false>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
                               [&](int, const int idx[4], T y[4], bool live, NoFetch) {
       if (live) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) *at_boff(dst, tile_boff<C>(row, idx[t])) = y[t];
+        for (int t = 0; t < 4; ++t) *at_boff(dst, tile_boff<C>(launder(row), idx[t])) = y[t];
       }
     }, [](int, const int*, T*, bool) {});
-  };
-  transform(re, im, Ta);
-  __builtin_amdgcn_sched_barrier(0);
-  transform(mre, mim, T1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   const double tot = block_sum(s2, red);
   if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
 }
@@ -439,23 +460,27 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     }
     const T RT = (T)dc.RT, BRT = (T)dc.BRT, B = (T)dc.B, A0 = (T)dc.A0, A1 = (T)dc.A1;
     const double mean = mean_u, thr = dc.threshold;
-    double sE = 0.0, sPS = 0.0, cSA = 0.0, s2 = 0.0;
-    // One domain check per grid point (numpy: log of a non-positive number is NaN / -inf, which
-    // the reference turns into its NaN assertion, timedata.py:10): the sums are poisoned at the end.
-    int bad = 0;
+    double sE = 0.0, sPS = 0.0, s2 = 0.0;
+    int cSA = 0;
+    // Domain (numpy: log of a non-positive number is NaN / -inf, which the reference turns into its NaN
+    // assertion, timedata.py:10): the table index of the logs doubles as the check (chs_log_unit_tab),
+    // one integer maximum per log; the sums are poisoned at the end.
+    unsigned dom = 0;
     auto point = [&](T& u) {
       const T uinv = T(1) - u;
-      bad |= ((u > T(0)) && (uinv > T(0))) ? 0 : 1;
       T lU, lV;
 #ifdef CHS_DIAG_NOLOG  // timing experiment only (wrong results): what the two logarithms cost
       lU = u; lV = uinv;
 #else
-      if constexpr (CHS_LOG_TABLE) { lU = chs_log_pos_tab<T>(u, ltab); lV = chs_log_pos_tab<T>(uinv, ltab); }
-      else { lU = chs_log_pos<T>(u); lV = chs_log_pos<T>(uinv); }
+      if constexpr (CHS_LOG_TABLE) { lU = chs_log_unit_tab<T>(u, ltab, dom); lV = chs_log_unit_tab<T>(uinv, ltab, dom); }
+      else {
+        dom = max(dom, ((u > T(0)) && (uinv > T(0))) ? 0u : ~0u);
+        lU = chs_log_pos<T>(u); lV = chs_log_pos<T>(uinv);
+      }
 #endif
       sE += (double)chs_energy_from_logs_fast<T>(u, uinv, lU, lV, RT, B, A0, A1);
       sPS += fabs((double)u - mean);
-      cSA += ((double)u < thr) ? 1.0 : 0.0;
+      cSA += ((double)u < thr) ? 1 : 0;
       if constexpr (FUSE) {
         const T m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
         s2 += (double)m * (double)m;
@@ -466,7 +491,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       }
       // ... and the running sums: otherwise the compiler postpones all 2E energy terms
       // (keeping log U, log(1-U), 1-U of every point alive) to add them up at the end
-      asm volatile("" : "+v"(sE), "+v"(sPS), "+v"(cSA), "+v"(bad));
+      asm volatile("" : "+v"(sE), "+v"(sPS), "+v"(cSA), "+v"(dom));
     };
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
@@ -474,8 +499,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       point(im[e]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (bad) sE = __builtin_nan("");  // U left (0,1): the record of this step becomes NaN
-    acc[0] = sE; acc[1] = sEdge; acc[2] = sPS; acc[3] = cSA; acc[4] = s2;
+    if (dom > (unsigned)(CHS_LOGTAB_N - 1)) sE = __builtin_nan("");  // U left (0,1): the record of this step becomes NaN
+    acc[0] = sE; acc[1] = sEdge; acc[2] = sPS; acc[3] = (double)cSA; acc[4] = s2;
   }
   if constexpr (ADAPT) {
     // Adaptive step (solver.py:177-183): on the steps whose successor re-evaluates delt, the column
@@ -999,7 +1024,12 @@ struct Launch {
         if (E->tailDeferred) {
           ta = chs_tail_args(E, E->tailSet, 1);
           g = grid + 1;
+        } else if (E->preRider) {
+          ta = chs_tail_args(E, -1, 1);
+          ta.pre_only = 1;
+          g = grid + 1;
         }
+        E->preRider = false;
         ta.reverse = (CHS_COL_ZIGZAG && (E->stepCount & 1)) ? 1 : 0;
         ++E->stepCount;
         k_col<CC, MODE_STEP><<<g, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
@@ -1311,7 +1341,11 @@ int chs_fast_step(Engine* E, bool first, bool last) {
     if (E->dc.adaptive_time) {
       if ((rc = chs_launch_mu_colsums(E, 0))) return rc;
     }
-    if ((rc = chs_launch_pre(E))) return rc;
+    if (defer) {
+      E->preRider = true;  // rides as the extra workgroup of this step's k_col (no launch of its own)
+    } else {
+      if ((rc = chs_launch_pre(E))) return rc;
+    }
   }
   chs_slot_begin(E, SLOT_SPEC);
   // T2 (columns inverted) overwrites T1 in place: every workgroup of k_col reads exactly the part

@@ -111,40 +111,49 @@ __device__ __forceinline__ double chs_log_ratio_f64(double a, double b) {
   return ok ? res : __builtin_nan("");  // every non-finite case ends in the NaN assertion anyway
 }
 
-// Table-driven log for x > 0 (no division): x = 2^e m, m in [sqrt(1/2), sqrt(2)); i = rint(256 m);
-// r = fma(m, rc_i, -1) with rc_i = fl(256/i) from the table (|r| <= 2.8e-3);
-// log x = (e ln2_hi + lc_i) + (e ln2_lo + log1p(r)), lc_i = fl(-log rc_i), log1p by its series to r^7
-// (truncation r^7/8 < 2e-19 relative).  `tab` = chs_log_table copied to LDS.  21 VALU + one LDS read
-// against 27 incl. a quarter-rate reciprocal for chs_log_pos_f64; same accuracy class (test_gpu_math).
+// Table-driven log for the fused row kernel's pointwise part (no division, no domain selects):
+//   x = 2^e m, m in [1/2, 1) (frexp);  i = rint(256 m) in [128, 256];  r = fma(m, rc_i, -1) with
+//   rc_i = fl(256/i) from the table (|r| <= 1/256);  log x = (e ln2 + lc_i) + log1p(r), lc_i = fl(-log rc_i),
+//   log1p by its series to r^6 (truncation r^7/7 < 2e-18).  `tab` = chs_log_table copied to LDS.
+// 13 floating-point + 3 integer instructions and one LDS read.
+// Accuracy: for 0 < x <= 1 -- all the timestep ever asks for: x = U or 1-U -- every term has the same
+// sign (e <= 0, lc_i <= 0) and the result is within 2.5 ulp (tests/test_gpu_math.py); x -> 1 gives
+// e = 0, i = 256, lc = 0: log x = log1p(r) with r = x - 1 exactly.  For x > 1 the terms e ln2 > 0 and
+// lc_i < 0 cancel: the ABSOLUTE error stays ~2e-16 max(1, |log x|) but the relative error grows as
+// log x -> 0+; ln2 is a single constant (no hi/lo split) because of that sign structure.
+// Domain: the index doubles as the domain check.  For finite x > 0 it lies in [128, 256]; x <= 0 gives
+// m <= 0 and an index below 128 (-> huge as unsigned), which `domain` (a running unsigned maximum of
+// i - 128, to be compared with 128 once per row) records: the caller turns the sums into NaN then,
+// like numpy's log of a non-positive number does for the reference (timedata.py:10).  NaN and +inf
+// propagate through r.
 #include "chs_log_table.h"
-__device__ __forceinline__ double chs_log_pos_tab_f64(double x, const double2* tab) {
+#define CHS_LN2 0.6931471805599453
+__device__ __forceinline__ double chs_log_unit_tab_f64(double x, const double2* tab, unsigned& domain) {
 #pragma clang fp contract(off)
-  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
-  int e = __builtin_amdgcn_frexp_exp(x);
-  const int c = (m < CHS_SQRT1_2) ? 1 : 0;
-  m = __builtin_ldexp(m, c);                  // [sqrt(1/2), sqrt(2))
-  e -= c;
+  const double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  const int e = __builtin_amdgcn_frexp_exp(x);
   const double u = __builtin_fma(m, 256.0, 0x1.8p52);  // the low word of 1.5*2^52 + n is n
-  int i = __double2loint(u) - CHS_LOGTAB_I0;
-  i = min(max(i, 0), CHS_LOGTAB_N - 1);                 // (x <= 0 or NaN: any entry; the caller flags the domain)
-  const double2 t = tab[i];
+  const unsigned i = (unsigned)(__double2loint(u) - CHS_LOGTAB_I0);
+  domain = max(domain, i);
+  const double2 t = tab[min(i, (unsigned)(CHS_LOGTAB_N - 1))];
   const double r = __builtin_fma(m, t.x, -1.0);
-  double p = __builtin_fma(r, 1.0 / 7.0, -1.0 / 6.0);
-  p = __builtin_fma(r, p, 1.0 / 5.0);
+  double p = __builtin_fma(r, -1.0 / 6.0, 1.0 / 5.0);
   p = __builtin_fma(r, p, -1.0 / 4.0);
   p = __builtin_fma(r, p, 1.0 / 3.0);
   p = __builtin_fma(r, p, -0.5);
   const double lp = __builtin_fma(r * r, p, r);
-  const double k = (double)e;
-  return __builtin_fma(k, CHS_LN2_HI, t.y) + __builtin_fma(k, CHS_LN2_LO, lp);
+  return __builtin_fma((double)e, CHS_LN2, t.y) + lp;
 }
 
 template <typename T> __device__ __forceinline__ T chs_log_pos(T x);
 template <> __device__ __forceinline__ double chs_log_pos<double>(double x) { return chs_log_pos_f64(x); }
 template <> __device__ __forceinline__ float chs_log_pos<float>(float x) { return logf(x); }
-template <typename T> __device__ __forceinline__ T chs_log_pos_tab(T x, const double2* tab);
-template <> __device__ __forceinline__ double chs_log_pos_tab<double>(double x, const double2* tab) { return chs_log_pos_tab_f64(x, tab); }
-template <> __device__ __forceinline__ float chs_log_pos_tab<float>(float x, const double2*) { return logf(x); }
+template <typename T> __device__ __forceinline__ T chs_log_unit_tab(T x, const double2* tab, unsigned& domain);
+template <> __device__ __forceinline__ double chs_log_unit_tab<double>(double x, const double2* tab, unsigned& domain) { return chs_log_unit_tab_f64(x, tab, domain); }
+template <> __device__ __forceinline__ float chs_log_unit_tab<float>(float x, const double2*, unsigned& domain) {
+  domain = max(domain, (x > 0.0f) ? 0u : ~0u);
+  return logf(x);
+}
 
 template <typename T> __device__ __forceinline__ T chs_log(T x);
 template <> __device__ __forceinline__ double chs_log<double>(double x) { return chs_log_f64(x); }
@@ -239,7 +248,8 @@ __device__ __forceinline__ T chs_spectral(T hatU, T hatMu, double li, double lj,
   const double CHeig = 1.0 + (lam2 * leig) * leig;
   const double Seig = lam1 * leig;
   const double rhs = (double)hatU + Seig * (double)hatMu;
-  // CHeig >= 1: reciprocal + two Newton steps + residual correction (error < 1 ulp of the
-  // correctly rounded quotient, measured) instead of the ~2x longer IEEE division sequence
-  return (T)chs_div_pos(rhs, CHeig);
+  // CHeig >= 1: reciprocal + one Newton step + residual correction (the correction squares the
+  // reciprocal's remaining error: < 1 ulp of the correctly rounded quotient, measured) instead of the
+  // ~2.5x longer IEEE division sequence
+  return (T)chs_div_pos1(rhs, CHeig);
 }

@@ -617,7 +617,8 @@ __global__ void k_test_math(int which, const double* __restrict__ a, const doubl
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double r;
-  if (which == 5) r = chs_log_pos_tab_f64(a[i], ltab);
+  unsigned dom = 0;
+  if (which == 5) { r = chs_log_unit_tab_f64(a[i], ltab, dom); if (dom > (unsigned)(CHS_LOGTAB_N - 1)) r = __builtin_nan(""); }
   else if (which == 0) r = chs_log_f64(a[i]);
   else if (which == 1) r = chs_log_ratio_f64(a[i], b[i]);
   else if (which == 4) r = chs_log_pos_f64(a[i]);

@@ -79,6 +79,7 @@ __device__ __forceinline__ void fin_update(const DevConsts& dc, DevState* st, do
 //   partMu[nMu]       = sum(mu^2) of the NEXT step's EnergieEut from k_row_inv (fused)
 struct TailArgs {
   int enabled = 0, do_pre = 0;
+  int pre_only = 0;  // first step of a call: no record yet, only the time-step control of the coming step
   int reverse = 0;  // (k_col rider, not a tail input) walk the column tiles in descending order this step
   DevConsts dc;
   const double* partDiag = nullptr; const double* partE2 = nullptr; const double* partMu = nullptr;
@@ -106,6 +107,24 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
   const bool adapt = do_pre && dc.adaptive_time && cs_next > 500 && (cs_next % 2) == 0;
   double v[NV] = {0, 0, 0, 0, 0, 0, 0, 0};  // sE, sEdge, sPS, cSA, spectral, musq, -, -
   double mn = 1.0e300;
+  if (ta.pre_only) {
+    // sum(mu^2) of the entry kernel -> L2 and the time bookkeeping of the first step (k_pre's work; fixed
+    // time step: nothing k_col of this step reads changes)
+    for (int i = tid; i < ta.nMu; i += THREADS) v[5] += ta.partMu[i];
+    v[5] = wave_sum(v[5]);
+    if (lane == 0) red[wave] = v[5];
+    __syncthreads();
+    if (tid == 0) {
+      double t = red[0];
+      for (int w = 1; w < NW; ++w) t += red[w];
+      DevState loc = *st;
+      pre_update(dc, &loc, t, false, 0.0);
+      st->delt = loc.delt; st->delt_coef = loc.delt_coef; st->time_delta_sum = loc.time_delta_sum;
+      st->time_passed = loc.time_passed; st->L2_cur = loc.L2_cur; st->lam1 = loc.lam1; st->lam2 = loc.lam2;
+      st->stop_reason = loc.stop_reason; st->halt = loc.halt;
+    }
+    return;
+  }
   for (int i = tid; i < ta.nRow; i += THREADS) {
     v[0] += ta.partDiag[(size_t)i * 4 + 0];
     v[1] += ta.partDiag[(size_t)i * 4 + 1];

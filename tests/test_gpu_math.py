@@ -39,20 +39,32 @@ def test_log_pos_accuracy(gpu):
     assert ulp_err(got[ok], ref[ok]).max() <= 2.5
 
 
-def test_log_pos_table_accuracy(gpu):
-    """The table-driven log (no division) of the fused row kernel's pointwise part."""
+def test_log_unit_table_accuracy(gpu):
+    """The table-driven log (no division, no selects) of the fused row kernel's pointwise part,
+    chs_log_unit_tab_f64: the kernel only ever asks for log U and log(1-U) with U in (0,1)."""
     rng = np.random.default_rng(5)
-    x = np.concatenate([rng.random(300000), 1 - rng.random(100000) * 1e-3, 1 - rng.random(50000) * 1e-9,
-                        np.exp(rng.uniform(-700, 700, 100000)), np.linspace(0.70, 0.72, 50001),
-                        np.linspace(0.99, 1.01, 200001), np.arange(181, 363) / 256.0,
-                        (np.arange(181, 363) + 0.5) / 256.0, np.nextafter((np.arange(181, 363) + 0.5) / 256.0, 0)])
-    x = x[x > 0]
+    grid = np.arange(128, 257) / 256.0
+    x = np.concatenate([rng.random(400000), 1 - rng.random(100000) * 1e-3, 1 - rng.random(50000) * 1e-9,
+                        np.exp(rng.uniform(-700, 0, 100000)), np.linspace(0.70, 0.72, 50001),
+                        np.linspace(0.49, 0.51, 50001), np.linspace(0.99, 1.0, 200001), grid,
+                        (grid[:-1] + 0.5 / 256.0), np.nextafter(grid[:-1] + 0.5 / 256.0, 0),
+                        2.0 ** -np.arange(1, 1000, 7.0), np.nextafter(2.0 ** -np.arange(1, 1000, 7.0), 0)])
+    x = x[(x > 0) & (x <= 1)]
     got = _lib.test_math(5, x)
     ref = np.log(np.asarray(x, dtype=np.longdouble)).astype(np.float64)
     ok = ref != 0
     e = ulp_err(got[ok], ref[ok])
     assert e.max() <= 2.5, (e.max(), x[ok][np.argmax(e)])
     assert np.all(got[x == 1.0] == 0.0)
+    # x > 1 (never asked for by the timestep): e ln2 and the table term cancel, the absolute error stays small
+    y = np.concatenate([1 + rng.random(100000), np.exp(rng.uniform(0, 700, 100000))])
+    goty = _lib.test_math(5, y)
+    refy = np.log(np.asarray(y, dtype=np.longdouble)).astype(np.float64)
+    assert np.max(np.abs(goty - refy) / np.maximum(1.0, np.abs(refy))) < 4e-16
+    # domain: the table index flags x <= 0 (the row kernel poisons its sums then); NaN and inf propagate
+    sp = _lib.test_math(5, np.array([0.0, -0.0, -1.0, -1e-300, -np.inf, np.nan, np.inf]))
+    assert np.all(np.isnan(sp[:6])) and not np.isfinite(sp[6])
+    assert np.all(np.isfinite(_lib.test_math(5, np.array([5e-324, 1e-310, 2.2250738585072014e-308]))))  # denormals are fine
 
 
 def test_log_ratio_accuracy(gpu):
