@@ -109,7 +109,7 @@ extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle*
   if (eng == CHS_ENGINE_AUTO) eng = chs_fast_supported(N, c->dtype) ? CHS_ENGINE_FAST : CHS_ENGINE_DIRECT;
   if (eng == CHS_ENGINE_FAST && !chs_fast_supported(N, c->dtype)) {
     delete E;
-    chs_set_error("chs_create: the fast engine needs N = 2^k in [128, 4096] (fp64) or N in {4096, 8192} (fp32)");
+    chs_set_error("chs_create: the fast engine needs N = 2^k in [128, 8192]");
     return CHS_EINVAL;
   }
   if (eng != CHS_ENGINE_FAST && eng != CHS_ENGINE_DIRECT) { delete E; chs_set_error("bad engine"); return CHS_EINVAL; }

@@ -1101,6 +1101,16 @@ using G8192C = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS,
 #endif
 using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, 4>;
 using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, 4>;
+// fp32 below N = 4096: the shapes of the fp64 configurations (groups inside one wavefront)
+using G128 = FCfg<float, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
+using G256 = FCfg<float, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
+using G512 = FCfg<float, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
+using G1024 = FCfg<float, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
+using G2048 = FCfg<float, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
+// fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
+// two rows or two of a tile's four columns per 512-thread workgroup)
+using F8192 = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 4, 4>;
+using F8192C = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 2, 4>;
 
 template <class C, class CC = C>
 static void bind(FastPlan* P) {
@@ -1114,8 +1124,8 @@ static void bind(FastPlan* P) {
 }
 
 bool chs_fast_supported(int N, int dtype) {
-  if (dtype == CHS_F32) return N == 4096 || N == 8192;
-  return N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096;
+  (void)dtype;  // both element types: N = 2^k, 128 <= N <= 8192
+  return N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192;
 }
 
 static void twiddle(long double num, long double den, long double& c, long double& s) {
@@ -1187,6 +1197,11 @@ int chs_fast_init(Engine* E) {
   FastPlan* P = new FastPlan();
   if (E->dtype == CHS_F32) {
     switch (E->N) {
+      case 128: bind<G128>(P); break;
+      case 256: bind<G256>(P); break;
+      case 512: bind<G512>(P); break;
+      case 1024: bind<G1024>(P); break;
+      case 2048: bind<G2048>(P); break;
       case 4096: bind<G4096, G4096C>(P); break;
       case 8192: bind<G8192, G8192C>(P); break;
       default: delete P; chs_set_error("fast engine (fp32): unsupported N"); return CHS_EINVAL;
@@ -1199,6 +1214,7 @@ int chs_fast_init(Engine* E) {
     case 1024: bind<F1024>(P); break;
     case 2048: bind<F2048>(P); break;
     case 4096: bind<F4096, F4096C>(P); break;
+    case 8192: bind<F8192, F8192C>(P); break;
     default: delete P; chs_set_error("fast engine: unsupported N"); return CHS_EINVAL;
   }
   E->dTw = P;

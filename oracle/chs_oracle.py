@@ -186,6 +186,12 @@ class OracleSolver:
             qrng = qmc.Sobol(d=N, seed=p.seed)
             self.create_rand = lambda n: qrng.random(n)
             self.U_init = p.XXX + (p.XXX * 0.01 * (self.create_rand(N) - 0.5))
+        elif p.generator == 'simplex':
+            # solver.py:72-75 (third-party `opensimplex`, requirements.txt: opensimplex~=0.4; not in this
+            # image: the import error surfaces here exactly as a missing dependency does in the reference)
+            import opensimplex
+            self.create_rand = lambda n: opensimplex.noise2array(np.linspace(0, 48, n), np.linspace(0, 48, n))
+            self.U_init = p.XXX + (p.XXX * 0.01 * (self.create_rand(N) - 0.5))
         else:
             rng = np.random.Generator(np.random.PCG64(p.seed))
             self.create_rand = lambda n: rng.random((n, n))

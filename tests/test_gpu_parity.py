@@ -18,7 +18,7 @@ from gpu_helpers import GOLD, KAPPA, RTOL, compare_run, make, relerr  # noqa: F4
 
 
 @pytest.mark.parametrize("engine,N", [('direct', 64), ('direct', 100), ('direct', 128), ('fast', 128), ('fast', 256),
-                                      ('fast', 512), ('fast', 1024), ('fast', 2048), ('fast', 4096)])
+                                      ('fast', 512), ('fast', 1024), ('fast', 2048), ('fast', 4096), ('fast', 8192)])
 def test_dctn_matches_scipy(gpu, engine, N):
     p = make(N, 2, engine)
     s = chsimpy_amd.Solver(p)
@@ -371,7 +371,7 @@ def test_ensemble_members_on_gpu(gpu, tmp_path):
 # (numpy defaults everywhere), so fp32 runs are validated against the fp64 path with a stated,
 # looser tolerance: per-step U within rtol 2e-4 and E within rtol 1e-5 after 560 steps.
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("N", [4096, 8192])
+@pytest.mark.parametrize("N", [128, 256, 512, 1024, 2048, 4096, 8192])
 def test_fp32_dctn(gpu, N):
     p = make(N, 2, 'fast', dtype='float32')
     s = chsimpy_amd.Solver(p, np.full((N, N), 0.5))
@@ -386,6 +386,33 @@ def test_fp32_dctn(gpu, N):
     Z = eng.dctn(Y, inverse=True)
     assert np.max(np.abs(Z - X)) < 2e-5 * np.max(np.abs(X))
     s.close()
+
+
+@pytest.mark.parametrize("N,nt", [(128, 200), (512, 200), (2048, 40)])
+def test_fp32_fast_engine_small_grids_vs_oracle(gpu, N, nt):
+    """fp32 on the fast engine below N=4096 (the ensemble size N=2048 among them) against the fp64 oracle.
+    The reference is float64 only: tolerance per step U rtol 2e-4, E rtol 1e-5 (as for the N=4096/8192
+    fp32 runs); the record's counters are exact."""
+    p = make(N, nt, 'fast', dtype='float32')
+    s = chsimpy_amd.Solver(p)
+    s.prepare()
+    sol = s.solve_or_resume()
+    assert s._engine.engine == 'fast'
+    o = orc.OracleSolver(orc.make_params(N, nt))
+    o.prepare()
+    o.solve_or_resume()
+    td, to = sol.timedata.data(), o.timedata.data()
+    assert td.shape == to.shape and np.array_equal(td[:, 0], to[:, 0])
+    assert np.allclose(sol.U, o.U, rtol=2e-4, atol=0), relerr(sol.U, o.U)
+    assert np.allclose(td[:, 1], to[:, 1], rtol=1e-5, atol=0)          # E
+    assert np.allclose(td[1:, 7], to[1:, 7], rtol=2e-3, atol=0)        # PS
+    assert sol.U.mean() == pytest.approx(o.U.mean(), rel=2e-6)          # mass conservation in fp32
+    s.close()
+
+
+def test_fp64_n8192_steps_vs_oracle(gpu):
+    """fp64 at N=8192 (four wavefronts per transform): a few steps against the oracle."""
+    compare_run(make(8192, 4, 'fast'), {})
 
 
 @pytest.mark.parametrize("N,dmax,dtype", [(2048, 2.4e-10, 'float64'), (4096, 1.2e-10, 'float64'),
