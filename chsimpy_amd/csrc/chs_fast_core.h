@@ -55,7 +55,11 @@ struct FCfg {
   static constexpr int SCR1 = (RA_ > 1) ? S1 * P1 : 0;
   static constexpr int SCR2 = (RB_ > 1) ? S2A * P2 : 0;
   static constexpr int SCRL = RL_ * PL;
-  static constexpr int SCR = (SCR1 > SCR2 ? (SCR1 > SCRL ? SCR1 : SCRL) : (SCR2 > SCRL ? SCR2 : SCRL));
+  // fp32: the real and the imaginary part of a value travel TOGETHER through the exchange scratch as one
+  // 8-byte item (half the LDS instructions and half the barriers of an exchange; the scratch then holds
+  // twice as many elements); fp64: one after the other through the same scratch (half the LDS)
+  static constexpr bool PAIR = (sizeof(T_) == 4);
+  static constexpr int SCR = (SCR1 > SCR2 ? (SCR1 > SCRL ? SCR1 : SCRL) : (SCR2 > SCRL ? SCR2 : SCRL)) * (PAIR ? 2 : 1);
   static constexpr bool WAVE_LOCAL = (G_ <= 64);  // a group inside one wavefront needs no s_barrier
   static_assert(L3 == RL_, "radices must multiply to M");
   static_assert(RA_ > 1 || RB_ == 1, "use RA before RB");
@@ -303,7 +307,8 @@ __device__ __forceinline__ void slot_adj(T y0, T y1, T y2, T y3, const SlotTw<T>
 
 // ---------------------------------------------------------------------------
 // LDS exchange helpers.  `scr` points at the group's scratch (C::SCR elements);
-// real and imaginary parts travel one after the other through the same scratch.
+// fp64: real and imaginary parts travel one after the other through the same scratch,
+// fp32 (C::PAIR): together, as one 8-byte item per value.
 // ---------------------------------------------------------------------------
 
 // ===========================================================================
@@ -353,12 +358,22 @@ __device__ __forceinline__ void mid_inv(typename C::T* re, typename C::T* im, co
 
 // ---- register <-> LDS movers; WR = true: registers -> LDS, false: LDS -> registers
 template <class C, bool WR>
-__device__ __forceinline__ void xfer(typename C::T& reg, typename C::T* scr, int addr) {
-  if constexpr (WR) scr[addr] = reg; else reg = scr[addr];
+__device__ __forceinline__ void xfer(typename C::T& reg, typename C::T& reg2, typename C::T* scr, int addr) {
+  if constexpr (C::PAIR) {
+    float2* s2 = reinterpret_cast<float2*>(scr);
+    if constexpr (WR) {
+      s2[addr] = make_float2(reg, reg2);
+    } else {
+      const float2 t = s2[addr];
+      reg = t.x; reg2 = t.y;
+    }
+  } else {
+    if constexpr (WR) scr[addr] = reg; else reg = scr[addr];
+  }
 }
 // pass-0 results (q,b,k) <-> X1[k][m_b]   (or XL[m_b][k] when there is no middle pass)
 template <class C, bool WR>
-__device__ __forceinline__ void mv_pass0(typename C::T* v, typename C::T* scr, int l) {
+__device__ __forceinline__ void mv_pass0(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
     const int m1 = l + C::G * q;
@@ -367,70 +382,70 @@ __device__ __forceinline__ void mv_pass0(typename C::T* v, typename C::T* scr, i
       const int m = b ? (C::L1 - 1 - m1) : m1;
 #pragma unroll
       for (int k = 0; k < C::R0; ++k) {
-        if constexpr (C::RA > 1) xfer<C, WR>(v[(q * 2 + b) * C::R0 + k], scr, k * C::P1 + m);
-        else xfer<C, WR>(v[(q * 2 + b) * C::R0 + k], scr, m * C::PL + k);
+        if constexpr (C::RA > 1) xfer<C, WR>(v[(q * 2 + b) * C::R0 + k], w[(q * 2 + b) * C::R0 + k], scr, k * C::P1 + m);
+        else xfer<C, WR>(v[(q * 2 + b) * C::R0 + k], w[(q * 2 + b) * C::R0 + k], scr, m * C::PL + k);
       }
     }
   }
 }
 // pass-A operands (ib,j) <-> X1[kappa][mm + L2*j]
 template <class C, bool WR>
-__device__ __forceinline__ void mv_a_in(typename C::T* v, typename C::T* scr, int l) {
+__device__ __forceinline__ void mv_a_in(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
 #pragma unroll
   for (int ib = 0; ib < C::NBA; ++ib) {
     const int id = l + C::G * ib;
     const int kap = id % C::S1, mm = id / C::S1;
 #pragma unroll
-    for (int j = 0; j < C::RA; ++j) xfer<C, WR>(v[ib * C::RA + j], scr, kap * C::P1 + mm + C::L2 * j);
+    for (int j = 0; j < C::RA; ++j) xfer<C, WR>(v[ib * C::RA + j], w[ib * C::RA + j], scr, kap * C::P1 + mm + C::L2 * j);
   }
 }
 // pass-A results (ib,k) <-> X2[kappa + S1*k][mm]   (or XL[mm][kappa + S1*k] when pass B is absent)
 template <class C, bool WR>
-__device__ __forceinline__ void mv_a_out(typename C::T* v, typename C::T* scr, int l) {
+__device__ __forceinline__ void mv_a_out(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
 #pragma unroll
   for (int ib = 0; ib < C::NBA; ++ib) {
     const int id = l + C::G * ib;
     const int kap = id % C::S1, mm = id / C::S1;
 #pragma unroll
     for (int k = 0; k < C::RA; ++k) {
-      if constexpr (C::RB > 1) xfer<C, WR>(v[ib * C::RA + k], scr, (kap + C::S1 * k) * C::P2 + mm);
-      else xfer<C, WR>(v[ib * C::RA + k], scr, mm * C::PL + kap + C::S1 * k);
+      if constexpr (C::RB > 1) xfer<C, WR>(v[ib * C::RA + k], w[ib * C::RA + k], scr, (kap + C::S1 * k) * C::P2 + mm);
+      else xfer<C, WR>(v[ib * C::RA + k], w[ib * C::RA + k], scr, mm * C::PL + kap + C::S1 * k);
     }
   }
 }
 // pass-B operands (ib,j) <-> X2[kappa][mm + L3*j]
 template <class C, bool WR>
-__device__ __forceinline__ void mv_b_in(typename C::T* v, typename C::T* scr, int l) {
+__device__ __forceinline__ void mv_b_in(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
 #pragma unroll
   for (int ib = 0; ib < C::NBB; ++ib) {
     const int id = l + C::G * ib;
     const int kap = id % C::S2A, mm = id / C::S2A;
 #pragma unroll
-    for (int j = 0; j < C::RB; ++j) xfer<C, WR>(v[ib * C::RB + j], scr, kap * C::P2 + mm + C::L3 * j);
+    for (int j = 0; j < C::RB; ++j) xfer<C, WR>(v[ib * C::RB + j], w[ib * C::RB + j], scr, kap * C::P2 + mm + C::L3 * j);
   }
 }
 // pass-B results (ib,k) <-> XL[mm][kappa + S2A*k]
 template <class C, bool WR>
-__device__ __forceinline__ void mv_b_out(typename C::T* v, typename C::T* scr, int l) {
+__device__ __forceinline__ void mv_b_out(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
 #pragma unroll
   for (int ib = 0; ib < C::NBB; ++ib) {
     const int id = l + C::G * ib;
     const int kap = id % C::S2A, mm = id / C::S2A;
 #pragma unroll
-    for (int k = 0; k < C::RB; ++k) xfer<C, WR>(v[ib * C::RB + k], scr, mm * C::PL + kap + C::S2A * k);
+    for (int k = 0; k < C::RB; ++k) xfer<C, WR>(v[ib * C::RB + k], w[ib * C::RB + k], scr, mm * C::PL + kap + C::S2A * k);
   }
 }
 // last-pass operands (q,b,j) <-> XL[j][kappa_b]
 template <class C, bool WR>
-__device__ __forceinline__ void mv_last(typename C::T* v, typename C::T* scr, int l) {
+__device__ __forceinline__ void mv_last(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
 #pragma unroll
   for (int q = 0; q < C::NP2; ++q) {
     int k1, k2; bool sp;
     Own<C>::last_pair(l, q, k1, k2, sp);
 #pragma unroll
     for (int j = 0; j < C::RL; ++j) {
-      xfer<C, WR>(v[(q * 2 + 0) * C::RL + j], scr, j * C::PL + k1);
-      xfer<C, WR>(v[(q * 2 + 1) * C::RL + j], scr, j * C::PL + k2);
+      xfer<C, WR>(v[(q * 2 + 0) * C::RL + j], w[(q * 2 + 0) * C::RL + j], scr, j * C::PL + k1);
+      xfer<C, WR>(v[(q * 2 + 1) * C::RL + j], w[(q * 2 + 1) * C::RL + j], scr, j * C::PL + k2);
     }
   }
 }
@@ -438,8 +453,12 @@ __device__ __forceinline__ void mv_last(typename C::T* v, typename C::T* scr, in
 // one exchange: WRITER moves the registers out, READER brings the new ownership in
 #define CHS_EXCHANGE(WRITER, READER)              \
   do {                                            \
-    xsync<C>(); WRITER(re, scr, l); xsync<C>(); READER(re, scr, l); \
-    xsync<C>(); WRITER(im, scr, l); xsync<C>(); READER(im, scr, l); \
+    if constexpr (C::PAIR) {                      \
+      xsync<C>(); WRITER(re, im, scr, l); xsync<C>(); READER(re, im, scr, l); \
+    } else {                                      \
+      xsync<C>(); WRITER(re, re, scr, l); xsync<C>(); READER(re, re, scr, l); \
+      xsync<C>(); WRITER(im, im, scr, l); xsync<C>(); READER(im, im, scr, l); \
+    }                                             \
   } while (0)
 
 // Forward: pass-0 operands in -> last-pass outputs Z out (index ((q*2+b)*RL + k)).
