@@ -1070,7 +1070,10 @@ using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 #ifndef CHS_ROW_PADL
 #define CHS_ROW_PADL 16
 #endif
-using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, CHS_ROW_PADL, CHS_ROW_WPS, 4>;
+#ifndef CHS_F4096_CT
+#define CHS_F4096_CT 4  // columns per tile of the T layout (8: 64-byte row pieces; measured)
+#endif
+using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, CHS_ROW_PADL, CHS_ROW_WPS, CHS_F4096_CT>;
 // k_col runs best with the full register file of two waves per SIMD (no spills; the compiler
 // uses the room to keep more loads in flight): measured 305 -> 191 us per launch
 #ifndef CHS_COL_WPS
@@ -1080,7 +1083,7 @@ using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, CHS_ROW
 #define CHS_COL_THREADS 256
 #endif
 // k_col: CHS_COL_THREADS/128 of the 4 columns of a tile per workgroup
-using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS, 4>;
+using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS, CHS_F4096_CT>;
 
 // fp32 configurations (BASELINE.json configs[3]: N = 8192 fp32): 32 complex values per lane
 // occupy the same 64 VGPRs as 16 fp64 ones; reductions and the spectral update stay in fp64.
