@@ -414,6 +414,10 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
     // solver.py:230 `domtime = self.time_passed ** (1 / 3)` with the host libm
     for (int64_t i = 0; i < done; ++i) rows[i * 9 + 4] = pow(rows[i * 9 + 4], 1.0 / 3.0);
   }
+  if (s.gate_timeout) {
+    chs_set_error("internal: a workgroup gave up waiting for the step's bookkeeping (gated tail)");
+    return CHS_EHIP;
+  }
   if (s.nan_flag) {
     chs_set_error("NaN in a recorded scalar (timedata.py:10): U left (0,1)");
     return CHS_ENAN;

@@ -34,6 +34,12 @@ struct DevState {
   int stop_reason;           // CHS_STOP_*
   int nan_flag;              // timedata.py:10
   int halt;                  // != 0: every later kernel of the call is a no-op
+  // Gated tail (chs_fast.hip, k_col<MODE_STEP>): the sequence number of the last bookkeeping that rode in
+  // a k_col as its extra workgroup and has been published (agent-scope release); the other workgroups of
+  // that launch wait for it in front of their spectral stage.  gate_timeout: a wait gave up (never seen).
+  unsigned long long decided;
+  int gate_timeout;
+  int pad_;
 };
 
 // Read-only scalars, passed to kernels by value.
@@ -176,6 +182,8 @@ struct Engine {
   double* partSet[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // Diag, Mu, E2, Ra
   int parity = 0;
   bool tailDeferred = false;  // the tail of the previous step is still to run
+  bool tailGated = false;     // ... and the other workgroups of that k_col wait for its decision (stop rules, adaptive dt)
+  unsigned long long gateSeq = 0;
   bool preRider = false;      // the first step's time-step control rides in its k_col (deferred-tail mode)
   unsigned stepCount = 0;     // k_col<MODE_STEP> launches so far (tile walk direction alternates)
   // jitter noise generated on the device: numpy's PCG64 stream continued from the host generator's state

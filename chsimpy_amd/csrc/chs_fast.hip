@@ -183,6 +183,9 @@ __device__ __forceinline__ void stagger_start() {
 #ifndef CHS_COL_LDS_PAD
 #define CHS_COL_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower k_col's occupancy
 #endif
+#ifndef CHS_GATED_TAIL
+#define CHS_GATED_TAIL 1  // 0: modes that can stop a call early run the bookkeeping as a kernel of its own per step
+#endif
 #ifndef CHS_COL_PIPE
 #define CHS_COL_PIPE 1     // recombine<PIPE>: 1 = next slot's loads ahead of this slot's stores, 2 = a slot earlier
 #endif
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   T* hcol = hat + (size_t)kc * C::N;
   // constants of the spectral stage, requested here: their latency disappears behind the stage-in
   // (loaded where they are used they cost every workgroup ~4 K cycles of waiting)
-  const double lam1 = st->lam1, lam2 = st->lam2;
+  double lam1 = st->lam1, lam2 = st->lam2;  // (gated launches read them again behind the gate)
   // (the column index is wave-uniform when a group fills whole wavefronts: scalar loads, no VGPRs)
   const int kc_u = (C::G >= 64) ? __builtin_amdgcn_readfirstlane(kc) : kc;
   const double lc = lam[kc_u];
@@ -794,6 +797,15 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     }
     fwd_passes<C>(re, im, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 2);
+    if constexpr (MODE == MODE_STEP) {
+      // Gated tail: the bookkeeping of the previous step -- stop rules, adaptive time step -- runs as block 0
+      // of THIS launch; nothing has been written yet (staging and forward passes only read), so wait for its
+      // decision here: stopped -> leave hat_U, T and the partial sums as the previous step left them
+      // (run_steps rebuilds U from hat_U); otherwise take this step's coefficients from it.
+      if (ta.gate) {
+        if (gate_wait(st, ta.seq, lam1, lam2)) return;
+      }
+    }
     if constexpr (PARK) {
       __syncthreads();  // every wavefront has read its last exchange: the scratch is free
       T hlate[C::E];
@@ -1024,6 +1036,7 @@ struct Launch {
         if (E->tailDeferred) {
           ta = chs_tail_args(E, E->tailSet, 1);
           g = grid + 1;
+          if (E->tailGated) { ta.gate = 1; ta.seq = ++E->gateSeq; }
         } else if (E->preRider) {
           ta = chs_tail_args(E, -1, 1);
           ta.pre_only = 1;
@@ -1385,8 +1398,13 @@ int chs_fast_step(Engine* E, bool first, bool last) {
     // this step has not advanced computed_steps yet, hence the offset
     if ((rc = fa ? chs_launch_colmin_rows(E, 1) : chs_launch_mu_colsums(E, 1))) return rc;
   }
-  if (last || !defer) return chs_launch_step_tail(E, last ? 0 : 1);
+  // Stop rules armed (energy rule, time limit) or an adaptive time step: the bookkeeping still rides in the
+  // next k_col, whose other workgroups wait for its decision in front of their first global write (gated
+  // tail, gate_wait) -- no 14 us one-block launch per step.  A run being profiled keeps the separate launch.
+  const bool gate = !defer && !E->timer.on && E->partSet[0][0] != nullptr && CHS_GATED_TAIL;
+  if (last || (!defer && !gate)) return chs_launch_step_tail(E, last ? 0 : 1);
   E->tailDeferred = true;
+  E->tailGated = gate;
   E->tailSet = E->parity;
   E->parity ^= 1;
   return CHS_OK;

@@ -79,6 +79,8 @@ __device__ __forceinline__ void fin_update(const DevConsts& dc, DevState* st, do
 //   partMu[nMu]       = sum(mu^2) of the NEXT step's EnergieEut from k_row_inv (fused)
 struct TailArgs {
   int enabled = 0, do_pre = 0;
+  int gate = 0;                   // publish the decision to the other workgroups of the carrying k_col launch
+  unsigned long long seq = 0;     // ... under this sequence number (DevState::decided)
   int pre_only = 0;  // first step of a call: no record yet, only the time-step control of the coming step
   int reverse = 0;  // (k_col rider, not a tail input) walk the column tiles in descending order this step
   DevConsts dc;
@@ -190,5 +192,36 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
     st->computed_steps = loc.computed_steps; st->rows_written = loc.rows_written;
     st->skip_check = loc.skip_check; st->stop_reason = loc.stop_reason; st->nan_flag = loc.nan_flag;
     st->halt = loc.halt;
+    if (ta.gate) {
+      // everything above becomes visible at agent scope before the sequence number does: the waiting
+      // workgroups (any CU, any XCD) read halt / lam1 / lam2 with agent-scope loads behind it
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(&st->decided, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+}
+
+// The other side of the gate: called by every thread of a workgroup of the carrying k_col launch in front of
+// its first global write.  Returns the published halt flag and the coefficients of this step.  One lane
+// polls (the bookkeeping workgroup is block 0, dispatched first, and waits for nobody: it always gets
+// there; by the time a tile workgroup has staged and transformed its tile it has long finished), bounded.
+__device__ __forceinline__ int gate_wait(DevState* __restrict__ st, unsigned long long seq, double& lam1, double& lam2) {
+  if (threadIdx.x == 0) {
+    int it = 0;
+    while (__hip_atomic_load(&st->decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++it > (1 << 20)) {  // ~1 s: cannot happen unless block 0 never ran; stop instead of hanging the device
+        st->gate_timeout = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  const int halt = __hip_atomic_load(&st->halt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int tmo = __hip_atomic_load(&st->gate_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  lam1 = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&st->lam1), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+  lam2 = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&st->lam2), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+  return halt | tmo;
 }
