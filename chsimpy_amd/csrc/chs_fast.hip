@@ -957,7 +957,7 @@ struct Launch {
   static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0) +
                                     (CHS_ROW_TW_LDS ? (size_t)row_tw_elems<C>() * sizeof(T) : 0) + CHS_ROW_LDS_PAD;
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
-  static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && C::R0 == 8;
+  static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && (C::R0 % 4 == 0);
   // + the parking area of half a hat_U column per lane (k_col<MODE_STEP>)
   static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (CHS_COL_PARK ? (size_t)CC::E * CC::THREADS : 0) +
                                      (CHS_COL_TW_LDS ? (size_t)col_tw_elems<CC>() : 0)) * sizeof(T) + CHS_COL_LDS_PAD;
@@ -1067,11 +1067,34 @@ struct Launch {
 };
 
 // fp64 configurations: <T, N, G, THREADS, R0, RA, RB, RL, pad1, pad2, padL, waves/SIMD>
+// Small grids are bound by one workgroup life per launch (a handful of workgroups, nothing to overlap
+// with): 8 complex values per lane instead of 16 -- radix-4 end passes -- halve the dependent
+// instruction stream of a lane and double the number of workgroups (CHS_SMALL_E8).
+#ifndef CHS_SMALL_E8
+#define CHS_SMALL_E8 1
+#endif
+#if CHS_SMALL_E8
+using F128 = FCfg<double, 128, 8, 256, 4, 4, 1, 4, 1, 0, 1, 2>;
+using F256 = FCfg<double, 256, 16, 256, 4, 8, 1, 4, 1, 0, 1, 2>;
+using F512 = FCfg<double, 512, 32, 256, 4, 4, 4, 4, 1, 1, 1, 2>;
+using F1024 = FCfg<double, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
+#else
 using F128 = FCfg<double, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
 using F256 = FCfg<double, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
 using F512 = FCfg<double, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
 using F1024 = FCfg<double, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
+#endif
+#ifndef CHS_F2048_E8
+#define CHS_F2048_E8 0
+#endif
+#if CHS_F2048_E8
+// two wavefronts per transform, 8 complex values per lane: twice the workgroups (the ensemble size)
+using F2048 = FCfg<double, 2048, 128, 256, 4, 8, 8, 4, 2, 1, 8, 4, 4>;
+using F2048C = FCfg<double, 2048, 128, 256, 4, 8, 8, 4, 2, 1, 8, 2, 4>;
+#else
 using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
+using F2048C = F2048;
+#endif
 // N = 4096: two wavefronts per transform, 16 complex values per lane, four radix passes
 #ifndef CHS_ROW_WPS
 #define CHS_ROW_WPS 4
@@ -1228,7 +1251,7 @@ int chs_fast_init(Engine* E) {
     case 256: bind<F256>(P); break;
     case 512: bind<F512>(P); break;
     case 1024: bind<F1024>(P); break;
-    case 2048: bind<F2048>(P); break;
+    case 2048: bind<F2048, F2048C>(P); break;
     case 4096: bind<F4096, F4096C>(P); break;
     case 8192: bind<F8192, F8192C>(P); break;
     default: delete P; chs_set_error("fast engine: unsupported N"); return CHS_EINVAL;

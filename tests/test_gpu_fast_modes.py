@@ -95,12 +95,13 @@ def test_energy_rule_full_sim_true_fast_engine(gpu, N, delt, stop):
     s.close()
 
 
-@pytest.mark.parametrize("N", [128, 256])
-@pytest.mark.parametrize("chunks", [(600,), (300, 300), (300, 221, 7, 72)])
+@pytest.mark.parametrize("N,chunks", [(128, (600,)), (128, (300, 300)), (128, (300, 221, 7, 72)),
+                                      (256, (600,)), (256, (300, 221, 7, 72)),
+                                      (1024, (520, 30, 50))])
 def test_adaptive_time_fast_engine(gpu, N, chunks):
     """adaptive_time on the fused pipeline (integrand column sums added up inside the row kernel,
-    k_colmin_rows, lam1/lam2 regenerated on the device) against the oracle: the delt history to 1e-9,
-    U/E/E2 to 1e-8 -- in one call and in chunks.  A chunk that starts beyond step 500 exercises the
+    k_colmin_rows, lam1/lam2 regenerated on the device -- N >= 1024; the smaller grids sweep U with k_mu)
+    against the oracle: the delt history to 1e-9, U/E/E2 to 1e-8 -- in one call and in chunks.  A chunk that starts beyond step 500 exercises the
     reference's resume quirk: the call reloads the grids of params.delt (solver.py:154-155) while
     self.delt keeps its adapted value until the next even step re-evaluates it (185-193).
     delt_dyn is a column SUM (np.linalg.norm(.., ord=-1)) and grows with N: delt_max is scaled so that
