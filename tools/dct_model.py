@@ -267,7 +267,8 @@ if __name__ == '__main__':
     rng = np.random.default_rng(0)
     for (N, G, rad) in [(128, 4, (8, 8)), (256, 8, (8, 2, 8)), (512, 16, (8, 4, 8)), (1024, 32, (8, 8, 8)),
                         (2048, 64, (8, 16, 8)), (4096, 64, (16, 8, 16)), (8192, 64, (16, 16, 16)),
-                        (128, 8, (4, 4, 4)), (4096, 128, (8, 4, 8, 8)), (4096, 128, (8, 8, 4, 8)), (2048, 128, (8, 4, 4, 8)), (8192, 128, (16, 4, 4, 16))]:
+                        (128, 8, (4, 4, 4)), (256, 16, (4, 8, 4)), (512, 32, (4, 4, 4, 4)), (1024, 64, (4, 8, 4, 4)),
+                        (8192, 256, (8, 8, 8, 8)), (4096, 128, (8, 4, 8, 8)), (4096, 128, (8, 8, 4, 8)), (2048, 128, (4, 8, 8, 4)), (8192, 128, (16, 4, 4, 16))]:
         m = Model(N, G, rad)
         x = rng.standard_normal(N)
         X = m.forward(x)
