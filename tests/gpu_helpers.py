@@ -27,6 +27,14 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
 
 
+def log_line(text):
+    """Measured parity margins go to gpurun_out/parity.log on the GPU box (copied to profiles/ at round end)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'parity.log'), 'a') as f:
+            f.write(text.rstrip() + '\n')
+
+
 def _log_parity(p, engine, eu, cols):
     d = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'gpurun_out')
     if os.path.isdir(d):

@@ -12,7 +12,7 @@ import pytest
 
 import chsimpy_amd
 from oracle import chs_oracle as orc
-from gpu_helpers import KAPPA, RTOL, compare_run, make, relerr
+from gpu_helpers import KAPPA, RTOL, compare_run, log_line, make, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -31,9 +31,11 @@ RTOL_LONG = 1e-8
 RTOL_LONG_L2 = 400 * RTOL_LONG
 
 
-def close_long(td, to):
+def close_long(td, to, what=''):
     assert td.shape == to.shape
     errs = [relerr(td[:, c], to[:, c]) for c in range(9)]
+    log_line(f"{what}: rows {td.shape[0]} max rel err E={errs[1]:.3e} E2={errs[2]:.3e} Ra={errs[5]:.3e} L2={errs[6]:.3e} "
+             f"PS={errs[7]:.3e} delt={errs[8]:.3e}")
     for c in range(9):
         assert errs[c] <= (RTOL_LONG_L2 if c == 6 else RTOL_LONG), (c, errs)
 
@@ -53,7 +55,7 @@ def test_energy_stop_full_sim_false_fast_engine(gpu, N, delt, stop):
     assert sol.stop_reason == o.stop_reason == 'energy'
     assert sol.computed_steps == o.computed_steps == stop and sol.tau0 == o.tau0 == stop
     assert sol.t0 == pytest.approx(o.t0, rel=1e-12)
-    close_long(sol.timedata.data(), o.timedata.data())
+    close_long(sol.timedata.data(), o.timedata.data(), f"energy stop full_sim=False fast N={N} delt={delt} (stop {stop}, U {relerr(sol.U, o.U):.3e})")
     assert np.allclose(sol.U, o.U, rtol=RTOL_LONG, atol=0), relerr(sol.U, o.U)
     # resume after the stop (hat_U re-derived from the rebuilt U, solver.py:159)
     for chunk in (1, 5, 30):
@@ -78,7 +80,7 @@ def test_energy_rule_full_sim_true_fast_engine(gpu, N, delt, stop):
     assert sol.stop_reason == o.stop_reason == 'None' and sol.computed_steps == o.computed_steps == nt
     assert sol.tau0 == o.tau0 == stop and sol.t0 == pytest.approx(o.t0, rel=1e-12)
     assert s.skip_check and o.skip_check
-    close_long(sol.timedata.data(), o.timedata.data())
+    close_long(sol.timedata.data(), o.timedata.data(), f"energy rule full_sim=True fast N={N} delt={delt} (tau0 {stop}, U {relerr(sol.U, o.U):.3e})")
     assert np.allclose(sol.U, o.U, rtol=RTOL_LONG, atol=0), relerr(sol.U, o.U)
     s.close()
     # ... and cut into calls around the maximum: skip_check survives the calls (solver.py:50,249)
@@ -120,6 +122,8 @@ def test_adaptive_time_fast_engine(gpu, N, chunks):
     assert np.allclose(td[:, 8], to[:, 8], rtol=1e-9, atol=0), relerr(td[:, 8], to[:, 8])
     for c in (1, 2, 4, 5, 6, 7):
         assert np.allclose(td[:, c], to[:, c], rtol=1e-8, atol=1e-300), (c, relerr(td[:, c], to[:, c]))
+    log_line(f"adaptive fast N={N} chunks={chunks}: max rel err delt={relerr(td[:, 8], to[:, 8]):.3e} E={relerr(td[:, 1], to[:, 1]):.3e} "
+             f"E2={relerr(td[:, 2], to[:, 2]):.3e} U={relerr(sol.U, o.U):.3e}")
     assert np.array_equal(td[:, 3], to[:, 3])                    # SA: a count
     assert np.allclose(sol.U, o.U, rtol=1e-8, atol=0), relerr(sol.U, o.U)
     assert s.delt == pytest.approx(o.delt, rel=1e-9) and s.time_passed == pytest.approx(o.time_passed, rel=1e-9)
