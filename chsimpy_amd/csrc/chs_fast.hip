@@ -183,6 +183,9 @@ __device__ __forceinline__ void stagger_start() {
 #ifndef CHS_COL_LDS_PAD
 #define CHS_COL_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower k_col's occupancy
 #endif
+#ifndef CHS_COL_DIRECT
+#define CHS_COL_DIRECT 0  // 1: k_col takes its tile rows straight into the quads of the lanes (half-wave swaps, no LDS staging): measured 8 % slower
+#endif
 #ifndef CHS_GATED_TAIL
 #define CHS_GATED_TAIL 1  // 0: modes that can stop a call early run the bookkeeping as a kernel of its own per step
 #endif
@@ -203,6 +206,18 @@ __device__ __forceinline__ int launder(int x) {
   __builtin_assume(x >= 0 && x < 1024);
   return x;
 }
+
+// a's upper half-wave <-> b's lower half-wave (v_permlane32_swap_b32, two per double): k_col's direct
+// tile access (below) pairs lane i (one column) with lane i+32 (the neighbouring column)
+__device__ __forceinline__ void swap_halves(double& a, double& b) {
+  const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+  a = __hiloint2double((int)r1[0], (int)r0[0]);
+  b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void swap_halves(float&, float&) {}  // (direct tile access is an fp64 path)
 
 // elements of the middle-pass twiddle tables twa | twb (contiguous, build_tables): what the fused row kernel can afford in LDS
 template <class C>
@@ -653,7 +668,23 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       bid -= 1;
     }
   }
-  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
+  // Direct tile access (fp64, two of a tile's four columns per workgroup, groups of whole wavefronts): a
+  // wavefront holds 32 lanes of EACH of the two columns -- lane i the first, lane i+32 the second, same
+  // butterfly index -- so that the 4 rows x 2 columns a pair of lanes needs are four 16-byte pieces of one
+  // 128-byte line: each lane loads two of them and one half-wave swap per register hands the neighbour its
+  // column.  No LDS staging, no staging barriers; HBM still sees 16-byte pieces at a 32-byte pitch, like
+  // the staged path (the other half of every 32 bytes belongs to the sibling workgroup of the tile).
+  constexpr bool DIRECT = (CHS_COL_DIRECT != 0) && sizeof(T) == 8 && C::C == 2 && C::CT == 4 && (C::G % 64 == 0) &&
+                          (CHS_COL_PARK == 0) && (CHS_COL_H0 == 0);
+  int l, sub;
+  if constexpr (DIRECT) {
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    sub = ln >> 5;
+    l = w * 32 + (ln & 31);
+  } else {
+    l = threadIdx.x % C::G;
+    sub = threadIdx.x / C::G;
+  }
   // tile and the part of it this workgroup owns; the Q workgroups of a tile get block numbers
   // b, b+8, ...: same XCD under round-robin dispatch (speed only, see row_of_block)
   int ct, hh;
@@ -691,7 +722,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // (loaded where they are used they cost every workgroup ~4 K cycles of waiting)
   double lam1 = st->lam1, lam2 = st->lam2;  // (gated launches read them again behind the gate)
   // (the column index is wave-uniform when a group fills whole wavefronts: scalar loads, no VGPRs)
-  const int kc_u = (C::G >= 64) ? __builtin_amdgcn_readfirstlane(kc) : kc;
+  const int kc_u = (C::G >= 64 && !DIRECT) ? __builtin_amdgcn_readfirstlane(kc) : kc;
   const double lc = lam[kc_u];
   const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc_u + 1] : 0.0;
   // What the spectral stage reads per recombination slot (4 positions of this lane): {lambda_kr,
@@ -727,6 +758,29 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   T* hpark2 = lds + threadIdx.x;
   T hearly[PARK ? C::E : 1];
   if constexpr (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE) {
+    if constexpr (DIRECT) {
+      // ---- tile rows -> quads, straight from HBM/L2 into the registers of the transform
+      const T* tile = Tin + (size_t)ct * C::N * C::CT + hh * C::C;
+#pragma unroll
+      for (int q = 0; q < C::NP0; ++q) {
+        const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+        for (int j = 0; j < C::R0 / 2; ++j) {
+          // rows 4m .. 4m+3 of the quad: this lane fetches rows 4m + 2 sub and 4m + 2 sub + 1, both columns
+          const T* p1 = tile + (size_t)(4 * (m1 + C::L1 * j) + 2 * sub) * C::CT;
+          const T* p2 = tile + (size_t)(4 * (m2 + C::L1 * j) + 2 * sub) * C::CT;
+          const double2 x1 = *reinterpret_cast<const double2*>(p1), y1 = *reinterpret_cast<const double2*>(p1 + C::CT);
+          const double2 x2 = *reinterpret_cast<const double2*>(p2), y2 = *reinterpret_cast<const double2*>(p2 + C::CT);
+          T q1[4] = {x1.x, y1.x, x1.y, y1.y}, q2[4] = {x2.x, y2.x, x2.y, y2.y};
+          // (x.x, x.y) = (column 0, column 1) of one row: the swap leaves row 4m (+1) of the lane's own column
+          // in .x and row 4m+2 (+3) in .y, in both half-waves
+          swap_halves(q1[0], q1[2]); swap_halves(q1[1], q1[3]);
+          swap_halves(q2[0], q2[2]); swap_halves(q2[1], q2[3]);
+          pack_quads<C>(q1, q2, q, j, re, im);
+        }
+      }
+      __syncthreads();  // (the pass twiddles copied to LDS above are visible from here on)
+    } else {
     // ---- stage in: tile rows -> quads of this group's column.  The whole tile is requested
     // first (one HBM latency for both rounds), then it passes through LDS half by half.
     const T* tile = Tin + (size_t)ct * C::N * C::CT;
@@ -786,6 +840,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       }
     }
     __syncthreads();
+    }
     if constexpr (MODE == MODE_STEP) STAMP(1, 1);
     if constexpr (PARK) {
 #pragma unroll
@@ -879,6 +934,27 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     inv_passes<C>(re, im, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 4);
     // ---- stage out: quads -> tile rows
+    if constexpr (DIRECT) {
+      T* tile = Tout + (size_t)ct * C::N * C::CT + hh * C::C;
+#pragma unroll
+      for (int q = 0; q < C::NP0; ++q) {
+        const int ld = launder(l);
+        const int m1 = ld + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+        for (int j = 0; j < C::R0 / 2; ++j) {
+          T q1[4], q2[4];
+          unpack_quads<C>(re, im, q, j, q1, q2);
+          swap_halves(q1[0], q1[2]); swap_halves(q1[1], q1[3]);   // back to (column 0, column 1) of two rows
+          swap_halves(q2[0], q2[2]); swap_halves(q2[1], q2[3]);
+          T* p1 = tile + (size_t)(4 * (m1 + C::L1 * j) + 2 * sub) * C::CT;
+          T* p2 = tile + (size_t)(4 * (m2 + C::L1 * j) + 2 * sub) * C::CT;
+          *reinterpret_cast<double2*>(p1) = make_double2(q1[0], q1[2]);
+          *reinterpret_cast<double2*>(p1 + C::CT) = make_double2(q1[1], q1[3]);
+          *reinterpret_cast<double2*>(p2) = make_double2(q2[0], q2[2]);
+          *reinterpret_cast<double2*>(p2 + C::CT) = make_double2(q2[1], q2[3]);
+        }
+      }
+    } else {
     T* tile = Tout + (size_t)ct * C::N * C::CT;
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
@@ -914,6 +990,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
           else *reinterpret_cast<float2*>(dst) = make_float2(a, b);
         }
       }
+    }
     }
   }
   if constexpr (MODE == MODE_STEP) {

@@ -594,7 +594,7 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
     // slots with the special lane's operands selected in (v_cndmask) plus one short slot for the
     // lane itself -- instead of a second, divergent pass over all slots for a single lane.
     bool has_special = false;
-    if (q == 0) has_special = (C::G < 64) || (__builtin_amdgcn_readfirstlane(l) < 64);
+    if (q == 0) has_special = (C::G < 64) || (__builtin_amdgcn_readfirstlane(l) == 0);  // (the wavefront that holds butterfly 0)
     if (!has_special) {
       SlotTw<T> wn;
       const int id0[4] = {kap, N - kap, M - kap, M + kap};
