@@ -32,3 +32,22 @@ def test_bench_fails_when_a_rank_fails():
     r = _run(['--gpus', '2', '--steps', '5', '--dry-run'], CHS_DIST_BACKEND='nccl')
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_bench_as_ranks_of_torch_distributed_run():
+    """The driver's N>1 invocation: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+    (RANK/WORLD_SIZE come from the launcher: bench.py must not start ranks of its own then)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, CHS_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '2', '--steps', '4', '--warmup', '1', '--dry-run'], env=e, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
