@@ -1210,19 +1210,25 @@ using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, 2, 1, 16, CH
 #ifndef CHS_G8192_THREADS
 #define CHS_G8192_THREADS 512
 #endif
-using G8192 = FCfg<float, 8192, 256, CHS_G8192_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, 4>;
-using G8192C = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS, 4>;
+#ifndef CHS_F32_CT
+#define CHS_F32_CT 8  // columns per tile of the fp32 T layout at N >= 4096: 32-byte row pieces as in fp64 (4: N=8192 23 % slower)
+#endif
+using G8192 = FCfg<float, 8192, 256, CHS_G8192_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT>;
+using G8192C = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
 #ifndef CHS_G4096_THREADS
 #define CHS_G4096_THREADS 256
 #endif
-using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, 4>;
-using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, 4>;
+using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, CHS_F32_CT>;
+using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, CHS_F32_CT>;
 // fp32 below N = 4096: the shapes of the fp64 configurations (groups inside one wavefront)
 using G128 = FCfg<float, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
 using G256 = FCfg<float, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
 using G512 = FCfg<float, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
+#ifndef CHS_F32_CT_SMALL
+#define CHS_F32_CT_SMALL 8  // N = 2048 fp32: 8 columns per tile (32-byte row pieces; +7 % against 4)
+#endif
 using G1024 = FCfg<float, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
-using G2048 = FCfg<float, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
+using G2048 = FCfg<float, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2, (CHS_F32_CT_SMALL ? CHS_F32_CT_SMALL : 4)>;
 // fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
 // two rows or two of a tile's four columns per 512-thread workgroup)
 using F8192 = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 4, 4>;
