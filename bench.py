@@ -211,6 +211,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # torch's lazy device initialisation takes milliseconds: have it behind us before anything is timed, so that
+    # the synchronisation in front of the timed region is the microseconds it should be (an idle gap of ~5 ms
+    # there sends the board's power management through a boost-then-throttle transient that lasts longer than
+    # the driver's 20 timed steps; tools/timeline.py on a kernel trace shows it)
+    sync()
+
     # warmup (untimed): W steps through the same C-ABI call as the timed region, so that nothing
     # (the 128 MB download of U at the end of Solver.solve_or_resume, tens of ms of an idle GPU)
     # sits between the warmup and the timed steps and lets the clocks drop.
