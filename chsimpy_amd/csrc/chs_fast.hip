@@ -1,1249 +1,14 @@
-// chs_fast.hip -- fast transform engine: three kernels per timestep.
-//
-//   k_row_fwd  reads U rows, evaluates EnergieEut (chsimpy/solver.py:166-175) on the fly,
-//              DCT-II along the row, writes T1                      [1 read + 1 write of N^2]
-//   k_col      reads a column tile of T1, DCT-II along the columns, semi-implicit spectral
-//              update of the carried hat_U (solver.py:201-206, utils.py:39-49 formed from
-//              the 1-D lambda table), DCT-III along the columns, writes T2
-//                                                                   [2 reads + 2 writes]
-//   k_row_inv  reads T2 rows, DCT-III along the row, writes U (solver.py:208)
-//                                                                   [1 read + 1 write]
-// = the 8 full-array transfers per timestep of SURVEY.md section 8(d).
-//
-// HBM layouts.  U is row-major (it is the boundary's array).  T1/T2 are "column-tile
-// major": element (r, k) lives at ((k / C) * N + r) * C + (k % C) with C = 256/G columns
-// per tile, so a column tile is one contiguous slab (k_col streams it with 16-byte
-// coalesced accesses through an LDS stage) while the row kernels touch it in C*8-byte
-// pieces, four consecutive rows (one workgroup) completing each 128-byte line.
-// hat_U lives in k_col's native order: for column kc, position p of lane l at
-// kc*N + p*G + l -- nobody else reads it.
-#include <cmath>
-#include <vector>
-#include <cstdlib>
-
-#include "chs_common.h"
+// chs_fast.hip -- fast transform engine, host side: plans, twiddle tables and the launch sequence of a
+// timestep.  The kernels are templates in chs_fast_kernels.h; their instantiations live in
+// chs_fast_f64.hip / chs_fast_f32.hip.
+#define CHS_FAST_MAIN_TU
+#include "chs_fast_kernels.h"
 #ifdef CHS_STAMPS
-#define CHS_NSTAMP 12
-__device__ unsigned long long g_stamps[2][8192 * CHS_NSTAMP];
-#define STAMP(K, I)                                                                         \
-  do {                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-    unsigned long long t__;                                                                 \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[K][blockIdx.x * CHS_NSTAMP + (I)] = t__; \
-  } while (0)
-// recombination-internal stamps of k_col<MODE_STEP> (the only PIPE user), slots 6..11
-#define CHS_RSTAMP(I) do { if constexpr (PIPE) STAMP(1, 6 + (I)); } while (0)
-// the same from wave 1 (the plain path), slots 10..11 + reuse: diagnostic builds only
-#define CHS_RSTAMP1(I)                                                                      \
-  do {                                                                                      \
-    if constexpr (PIPE) {                                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                    \
-      unsigned long long t__;                                                               \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");          \
-      __builtin_amdgcn_sched_barrier(0);                                                    \
-      if (threadIdx.x == 64 && blockIdx.x < 8192) g_stamps[0][blockIdx.x * CHS_NSTAMP + 7 + (I)] = t__; \
-    }                                                                                       \
-  } while (0)
-extern "C" int chs_debug_stamps(int which, unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n,
-                                  sizeof(unsigned long long) * 8192 * CHS_NSTAMP * which);
-}
-#else
-#define STAMP(K, I) do {} while (0)
-#define CHS_RSTAMP(I) do {} while (0)
-#define CHS_RSTAMP1(I) do {} while (0)
+// diagnostic build with phase stamps: one translation unit (the stamp buffer is a device variable)
+#define CHS_FAST_UNITY_INCLUDE
+#include "chs_fast_f64.hip"
+#include "chs_fast_f32.hip"
 #endif
-#include "chs_fast_core.h"
-#include "chs_tail.h"
-#include "chs_math.h"
-
-enum { MODE_STEP = 0, MODE_FWD_NATIVE = 1, MODE_FWD_NATURAL = 2, MODE_INV_NATURAL = 3, MODE_INV_NATIVE = 4 };
-
-template <class C>
-__device__ __forceinline__ size_t tile_addr(int r, int k) {
-  return ((size_t)(k / C::CT) * C::N + r) * C::CT + (k % C::CT);
-}
-// Element (r, k) of a tile-major array through a 32-bit BYTE offset from the (uniform) array base: the
-// access becomes `global_load/store v, voffset, s[base]` -- one or two integer instructions per address
-// instead of a 64-bit multiply-add chain.  N*N*sizeof(T) < 2^32 for every configuration (<= 512 MB).
-template <class C>
-__device__ __forceinline__ unsigned tile_boff(unsigned r, unsigned k) {
-  return (((k / C::CT) * C::N + r) * C::CT + (k % C::CT)) * (unsigned)sizeof(typename C::T);
-}
-template <typename T>
-__device__ __forceinline__ const T* at_boff(const T* base, unsigned boff) {
-  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + boff);
-}
-template <typename T>
-__device__ __forceinline__ T* at_boff(T* base, unsigned boff) {
-  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff);
-}
-
-// First row of a row-kernel workgroup.  CT consecutive rows share 128-byte lines of T1/T2; when
-// a workgroup holds fewer rows (C < CT) the CT/C workgroups of one line group are given block
-// numbers b, b+8, b+16, ... : workgroups are dealt round-robin over the 8 XCDs, so these land on
-// one XCD (one L2) and are dispatched back to back -- a speed matter only, never correctness.
-template <class C>
-__device__ __forceinline__ int row_of_block(int b) {
-  constexpr int Q = C::CT / C::C;
-  if constexpr (Q == 1) {
-    return b * C::C;
-  } else {
-    const int xcd = b & 7, j = b >> 3;
-    const int g = xcd + 8 * (j / Q), m = j % Q;
-    return g * C::CT + m * C::C;
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void load4(const T* p, T q[4]) {
-  if constexpr (sizeof(T) == 8) {
-    const double2 a = *reinterpret_cast<const double2*>(p);
-    const double2 b = *reinterpret_cast<const double2*>(p + 2);
-    q[0] = a.x; q[1] = a.y; q[2] = b.x; q[3] = b.y;
-  } else {
-    const float4 a = *reinterpret_cast<const float4*>(p);
-    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
-  }
-}
-template <typename T>
-__device__ __forceinline__ void store4(T* p, const T q[4]) {
-  if constexpr (sizeof(T) == 8) {
-    *reinterpret_cast<double2*>(p) = make_double2(q[0], q[1]);
-    *reinterpret_cast<double2*>(p + 2) = make_double2(q[2], q[3]);
-  } else {
-    *reinterpret_cast<float4*>(p) = make_float4(q[0], q[1], q[2], q[3]);
-  }
-}
-
-extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
-
-// Start-up stagger (experiment knob): every second workgroup of an XCD sleeps for
-// CHS_STAGGER x ~3.5 us before its first load, so that the memory phase of one half overlaps the
-// compute phase of the other (a kernel here has only 2-4 rounds of workgroups: no steady state).
-#ifndef CHS_STAGGER_UNIT
-#define CHS_STAGGER_UNIT 127
-#endif
-#ifndef CHS_STAGGER_ROW
-#define CHS_STAGGER_ROW 0
-#endif
-#ifndef CHS_STAGGER_COL
-#define CHS_STAGGER_COL 0
-#endif
-template <int NSLEEP>
-__device__ __forceinline__ void stagger_start() {
-  if constexpr (NSLEEP > 0) {
-    // Delay every other workgroup of an XCD's dispatch order (j = blockIdx / 8), flipped every 32:
-    // whether the dispatcher fills a CU first (j, j+1) or deals across the 32 CUs first (j, j+32),
-    // the two residents of a CU start half a phase apart and keep that offset round after round.
-    const int j = blockIdx.x >> 3;
-    if ((j ^ (j >> 5)) & 1) {
-#pragma unroll 1
-      for (int i = 0; i < NSLEEP; ++i) __builtin_amdgcn_s_sleep(CHS_STAGGER_UNIT);  // 64 cycles per unit
-    }
-  }
-}
-
-// ---- diagnostic build only (-DCHS_STAMPS): s_memtime stamps at the phase boundaries of the
-// row and column kernels, first wave of every workgroup; read back with chs_debug_stamps().
-// The stamp values go to a buffer nothing else reads; no output is computed from them.
-#ifndef CHS_ALWAYS_STORE_U
-#define CHS_ALWAYS_STORE_U 0  // 1: write U to HBM on every step even when nothing can read it
-#endif
-#ifndef CHS_ALIAS_T
-#define CHS_ALIAS_T 1
-#endif
-#ifndef CHS_COL_ZIGZAG
-#define CHS_COL_ZIGZAG 1
-#endif
-#ifndef CHS_LOG_TABLE
-#define CHS_LOG_TABLE 1  // table-driven log in the fused row kernel's pointwise part (0: division-based)
-#endif
-#ifndef CHS_COL_H0
-#define CHS_COL_H0 0  // 1: hat_U of slot 0 requested before the forward passes (measured neutral)
-#endif
-#ifndef CHS_COL_TW_LDS
-#define CHS_COL_TW_LDS 1  // k_col<MODE_STEP>: radix-pass twiddles from LDS
-#endif
-#ifndef CHS_ROW_LDS_PAD
-#define CHS_ROW_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower the row kernels' occupancy
-#endif
-#ifndef CHS_ROW_TW_LDS
-#define CHS_ROW_TW_LDS 0  // fused row kernel: middle-pass twiddles from LDS (needs CHS_ROW_PADL=4 to keep 4 workgroups per CU)
-#endif
-// ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
-#ifndef CHS_COL_PARK
-#define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
-#endif
-#ifndef CHS_COL_PRELOAD
-#define CHS_COL_PRELOAD 1  // 2: request the whole tile before staging it; 1: half by half (fewer registers, ~1 % faster)
-#endif
-#ifndef CHS_COL_LDS_PAD
-#define CHS_COL_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower k_col's occupancy
-#endif
-#ifndef CHS_COL_DIRECT
-#define CHS_COL_DIRECT 0  // 1: k_col takes its tile rows straight into the quads of the lanes (half-wave swaps, no LDS staging): measured 8 % slower
-#endif
-#ifndef CHS_GATED_TAIL
-#define CHS_GATED_TAIL 1  // 0: modes that can stop a call early run the bookkeeping as a kernel of its own per step
-#endif
-#ifndef CHS_COL_PIPE
-#define CHS_COL_PIPE 1     // recombine<PIPE>: 1 = next slot's loads ahead of this slot's stores, 2 = a slot earlier
-#endif
-#ifndef CHS_ROW_PIPE
-#define CHS_ROW_PIPE false
-#endif
-
-// Returns x through an opaque asm so that index arithmetic derived from it is not CSE'd
-// with (and kept alive since) an earlier phase of the kernel: recomputing a few integer
-// offsets is far cheaper than holding dozens of address registers across a phase.
-__device__ __forceinline__ int launder(int x) {
-  asm volatile("" : "+v"(x));
-  // lane / thread indices only: without the range the divisions and remainders by powers of two that
-  // the index maps are made of compile to signed sequences (4-5 instructions instead of one shift)
-  __builtin_assume(x >= 0 && x < 1024);
-  return x;
-}
-
-// a's upper half-wave <-> b's lower half-wave (v_permlane32_swap_b32, two per double): k_col's direct
-// tile access (below) pairs lane i (one column) with lane i+32 (the neighbouring column)
-__device__ __forceinline__ void swap_halves(double& a, double& b) {
-  const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
-  const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
-  const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-  const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-  a = __hiloint2double((int)r1[0], (int)r0[0]);
-  b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-__device__ __forceinline__ void swap_halves(float&, float&) {}  // (direct tile access is an fp64 path)
-
-// elements of the middle-pass twiddle tables twa | twb (contiguous, build_tables): what the fused row kernel can afford in LDS
-template <class C>
-constexpr int row_tw_elems() {
-  return 2 * ((C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
-}
-
-// ---------------------------------------------------------------------------
-// k_row_fwd: one group per row.  POINTWISE: the operand is EnergieEut(U) and the
-// block's sum(mu^2) is recorded (solver.py:225); otherwise a plain transform.
-// (Prologue of a solve_or_resume call, and the unfused/jitter path.)
-// ---------------------------------------------------------------------------
-template <class C, bool POINTWISE>
-__global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C::T* __restrict__ U, typename C::T* __restrict__ T1,
-                                                    FTables<typename C::T> tb, DevConsts dc,
-                                                    const DevState* __restrict__ st, double* __restrict__ partMu) {
-  using T = typename C::T;
-  __shared__ double red[32];
-  if (st->halt) return;
-  T* lds = reinterpret_cast<T*>(chs_dyn_lds);
-  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
-  const int row = row_of_block<C>(blockIdx.x) + sub;
-  T* scr = lds + (size_t)sub * C::SCR;
-  T re[C::E], im[C::E];
-  double s2 = 0.0;
-  const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
-  const unsigned urow = (unsigned)row * C::N;  // (32-bit offsets from the uniform base, see tile_boff)
-#pragma unroll
-  for (int q = 0; q < C::NP0; ++q) {
-    const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-    for (int j = 0; j < C::R0 / 2; ++j) {
-      T q1[4], q2[4];
-      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
-      pack_quads<C>(q1, q2, q, j, re, im);
-    }
-  }
-  if constexpr (POINTWISE) {
-#pragma unroll
-    for (int e = 0; e < C::E; ++e) {
-      re[e] = chs_mu<T>(re[e], RT, BRT, A0, A1);
-      im[e] = chs_mu<T>(im[e], RT, BRT, A0, A1);
-      s2 += (double)re[e] * (double)re[e] + (double)im[e] * (double)im[e];
-    }
-  }
-  fwd_passes<C>(re, im, scr, tb, l);
-  recombine<C, true, false, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
-                            [&](int, const int idx[4], T y[4], bool live, NoFetch) {
-    if (live) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) *at_boff(T1, tile_boff<C>(row, idx[t])) = y[t];
-    }
-  }, [](int, const int*, T*, bool) {});
-  if constexpr (POINTWISE) {
-    const double tot = block_sum(s2, red);
-    if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_row_fwd2: the entry of a solve_or_resume call on the fused pipeline in ONE launch:
-//   Ta <- row DCT-II of U            (the row half of hat_U = dctn(U), solver.py:159)
-//   T1 <- row DCT-II of EnergieEut(U) (what the fused row kernel of a previous step would have left)
-// and the block's sum(mu^2) (solver.py:225).  The two transforms run one after the other on the same
-// registers (four waves per SIMD like the other row kernels); the second pass re-reads the row of U
-// the workgroup has just read (L2), so HBM sees U once.  EnergieEut uses the shared-log form of the
-// fused row kernel (log U - log(1-U) from the table-driven log).
-// ---------------------------------------------------------------------------
-template <class C>
-__global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename C::T* __restrict__ U, typename C::T* __restrict__ Ta,
-                                                                 typename C::T* __restrict__ T1, FTables<typename C::T> tb,
-                                                                 DevConsts dc, const DevState* __restrict__ st,
-                                                                 double* __restrict__ partMu) {
-  using T = typename C::T;
-  __shared__ double red[32];
-  if (st->halt) return;
-  T* lds = reinterpret_cast<T*>(chs_dyn_lds);
-  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
-  const int row = row_of_block<C>(blockIdx.x) + sub;
-  T* scr = lds + (size_t)sub * C::SCR;
-  double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
-  if constexpr (CHS_LOG_TABLE && sizeof(T) == 8) {
-    for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
-    __syncthreads();
-  }
-  T re[C::E], im[C::E];
-  double s2 = 0.0;
-  unsigned dom = 0;
-  const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int lp = launder(l);
-    const unsigned urow = (unsigned)launder(row) * C::N;
-#pragma unroll
-    for (int q = 0; q < C::NP0; ++q) {
-      const int m1 = lp + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-      for (int j = 0; j < C::R0 / 2; ++j) {
-        T q1[4], q2[4];
-        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
-        pack_quads<C>(q1, q2, q, j, re, im);
-      }
-    }
-    if (pass == 1) {
-      auto mu = [&](T& u) {
-        const T uinv = T(1) - u;
-        T m;
-        if constexpr (CHS_LOG_TABLE) {
-          const T lU = chs_log_unit_tab<T>(u, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
-          m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
-        } else {
-          m = chs_mu<T>(u, RT, BRT, A0, A1);
-        }
-        s2 += (double)m * (double)m;
-        u = m;
-        asm volatile("" : "+v"(u), "+v"(s2), "+v"(dom));  // one grid point at a time (register pressure)
-      };
-#pragma unroll
-      for (int e = 0; e < C::E; ++e) { mu(re[e]); mu(im[e]); }
-      if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of the first step becomes NaN
-    }
-    T* dst = pass ? T1 : Ta;
-    fwd_passes<C>(re, im, scr, tb, launder(l));
-    recombine<C, true, false, false>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
-                              [&](int, const int idx[4], T y[4], bool live, NoFetch) {
-      if (live) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) *at_boff(dst, tile_boff<C>(launder(row), idx[t])) = y[t];
-      }
-    }, [](int, const int*, T*, bool) {});
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const double tot = block_sum(s2, red);
-  if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
-}
-
-// ---------------------------------------------------------------------------
-// k_row_inv: one group per row: T2 (tile-major) -> DCT-III -> U (row-major, solver.py:208).
-//   DIAG: while U is in registers, the pointwise part of the record of this step
-//         (solver.py:218-228): bulk energy density, |U - mean| and the U < threshold
-//         count, plus the column-edge terms of the gradient energy (the rest of E2
-//         comes from the spectrum, see k_col).  partDiag[block] = {sE, sEdge, sPS, cSA}.
-//   FUSE: the row then goes straight on to the next timestep: EnergieEut (solver.py:
-//         166-175, sharing log U and log(1-U) with the energy density), sum(mu^2), and
-//         the forward row DCT-II into T1 -- U is never re-read from HBM.
-// ---------------------------------------------------------------------------
-#ifndef CHS_LB_FUSED
-#define CHS_LB_FUSED 2
-#endif
-#ifndef CHS_LB_COL
-#define CHS_LB_COL 2
-#endif
-template <class C, bool DIAG, bool FUSE, bool ADAPT = false>
-__global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
-                                                    typename C::T* __restrict__ T1, FTables<typename C::T> tb,
-                                                    DevConsts dc, const DevState* __restrict__ st,
-                                                    double* __restrict__ partDiag, double* __restrict__ partMu,
-                                                    double* __restrict__ partRa, int store_u,
-                                                    double* __restrict__ partColRows = nullptr) {
-  using T = typename C::T;
-  __shared__ double red[64];
-  if (st->halt) return;
-  T* lds = reinterpret_cast<T*>(chs_dyn_lds);
-  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
-  if constexpr (DIAG && FUSE) stagger_start<CHS_STAGGER_ROW>();
-  const double mean_u = st->meanU;  // requested at entry (k_col of this step wrote it), used in the pointwise part
-  // reduction table of the table-driven log, behind the exchange scratch (visible after the first barrier)
-  double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
-  if constexpr (DIAG && CHS_LOG_TABLE && sizeof(T) == 8) {
-    for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
-    if constexpr (C::WAVE_LOCAL) __syncthreads();  // (no block barrier before the pointwise part otherwise)
-  }
-  // middle-pass twiddles (twa | twb) from LDS where the row kernel has room for them (CHS_ROW_TW_LDS)
-  FTables<T> tbp = tb;
-  if constexpr (DIAG && FUSE && CHS_ROW_TW_LDS && !C::WAVE_LOCAL) {
-    T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0));
-    constexpr int NTW = row_tw_elems<C>();
-    for (int i = 2 * threadIdx.x; i < NTW; i += 2 * C::THREADS) {
-      if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(ltw + i) = *reinterpret_cast<const double2*>(tb.twa + i);
-      else *reinterpret_cast<float2*>(ltw + i) = *reinterpret_cast<const float2*>(tb.twa + i);
-    }
-    tbp.twa = ltw;
-    tbp.twb = ltw + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
-  }
-  const int row0 = row_of_block<C>(blockIdx.x);
-  const int row = row0 + sub;
-  T* scr = lds + (size_t)sub * C::SCR;
-  T re[C::E], im[C::E];
-  if constexpr (DIAG && FUSE) STAMP(0, 0);
-  recombine<C, false, true, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
-                            [&](int, const int idx[4], T y[4], bool, NoFetch) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) y[t] = *at_boff(T2, tile_boff<C>(row, idx[t]));
-  }, [](int, const int*, T*, bool) {});
-  if constexpr (DIAG && FUSE) STAMP(0, 1);
-  inv_passes<C>(re, im, scr, tbp, launder(l));
-  if constexpr (DIAG && FUSE) STAMP(0, 2);
-  __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
-  const unsigned urow = (unsigned)row * C::N;
-  double sEdge = 0.0;
-  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  const int ls = launder(l);
-  // FUSE: between the steps of one call nothing reads U from HBM (the next step continues from the
-  // registers) except the tail's np.gradient row-edge terms, which look at rows 0, 1, N-2, N-1: with
-  // store_u == 0 only the workgroups owning those rows write them (chs_fast_step decides).
-  const bool write_u = !FUSE || store_u || row0 < 2 || row0 + C::C > C::N - 2;
-  if (write_u) {
-#pragma unroll
-    for (int q = 0; q < C::NP0; ++q) {
-      const int m1 = ls + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-      for (int j = 0; j < C::R0 / 2; ++j) {
-        T q1[4], q2[4];
-        unpack_quads<C>(re, im, q, j, q1, q2);
-        store4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-        store4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
-      }
-    }
-  }
-  if constexpr (DIAG) {
-    // np.gradient edge columns: (U[r,1]-U[r,0]) and (U[r,N-1]-U[r,N-2]) live in lane 0
-    if (ls == 0) {
-      T q1[4], q2[4];
-      unpack_quads<C>(re, im, 0, 0, q1, q2);
-      const double d0 = (double)q1[1] - (double)q1[0];
-      unpack_quads<C>(re, im, 0, C::R0 / 2 - 1, q1, q2);
-      const double d1 = (double)q2[3] - (double)q2[2];
-      sEdge += d0 * d0 + d1 * d1;
-    }
-  }
-  if constexpr (DIAG && FUSE) STAMP(0, 3);
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (DIAG) {
-    // Ra of row int(N/2)+1 (solver.py:226-227): only the workgroup that owns that row takes this
-    // block-uniform branch.  (The row-edge terms of np.gradient -- rows 0/1 and N-2/N-1 -- are
-    // added by the tail, which reads those four rows back from HBM: chs_tail.h.)
-    constexpr int RR = C::N / 2 + 1;
-    const bool ra_blk = (row0 == (RR / C::C) * C::C);
-    if (ra_blk) {
-      // Ra: mean absolute deviation of one row from its own mean (two passes over registers)
-      const bool mine = ra_blk && sub == RR % C::C;
-      double rs = 0.0;
-      if (mine) {
-#pragma unroll
-        for (int e = 0; e < C::E; ++e) rs += (double)re[e] + (double)im[e];
-      }
-      const double rmean = block_sum(rs, red) / (double)C::N;
-      double ad = 0.0;
-      if (mine) {
-#pragma unroll
-        for (int e = 0; e < C::E; ++e) ad += fabs((double)re[e] - rmean) + fabs((double)im[e] - rmean);
-      }
-      const double ra = block_sum(ad, red) / (double)C::N;
-      if (ra_blk && threadIdx.x == 0) partRa[0] = ra;
-      __syncthreads();
-    }
-    const T RT = (T)dc.RT, BRT = (T)dc.BRT, B = (T)dc.B, A0 = (T)dc.A0, A1 = (T)dc.A1;
-    const double mean = mean_u, thr = dc.threshold;
-    double sE = 0.0, sPS = 0.0, s2 = 0.0;
-    int cSA = 0;
-    // Domain (numpy: log of a non-positive number is NaN / -inf, which the reference turns into its NaN
-    // assertion, timedata.py:10): the table index of the logs doubles as the check (chs_log_unit_tab),
-    // one integer maximum per log; the sums are poisoned at the end.
-    unsigned dom = 0;
-    auto point = [&](T& u) {
-      const T uinv = T(1) - u;
-      T lU, lV;
-#ifdef CHS_DIAG_NOLOG  // timing experiment only (wrong results): what the two logarithms cost
-      lU = u; lV = uinv;
-#else
-      if constexpr (CHS_LOG_TABLE) { lU = chs_log_unit_tab<T>(u, ltab, dom); lV = chs_log_unit_tab<T>(uinv, ltab, dom); }
-      else {
-        dom = max(dom, ((u > T(0)) && (uinv > T(0))) ? 0u : ~0u);
-        lU = chs_log_pos<T>(u); lV = chs_log_pos<T>(uinv);
-      }
-#endif
-      sE += (double)chs_energy_from_logs_fast<T>(u, uinv, lU, lV, RT, B, A0, A1);
-      sPS += fabs((double)u - mean);
-      cSA += ((double)u < thr) ? 1 : 0;
-      if constexpr (FUSE) {
-        const T m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
-        s2 += (double)m * (double)m;
-        u = m;
-        // opaque use: finishes this grid point before the next one starts, so the
-        // intermediates (logs, 1-U, ...) of 128 points are never alive together
-        asm volatile("" : "+v"(u), "+v"(s2));
-      }
-      // ... and the running sums: otherwise the compiler postpones all 2E energy terms
-      // (keeping log U, log(1-U), 1-U of every point alive) to add them up at the end
-      asm volatile("" : "+v"(sE), "+v"(sPS), "+v"(cSA), "+v"(dom));
-    };
-#pragma unroll
-    for (int e = 0; e < C::E; ++e) {
-      point(re[e]);
-      point(im[e]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (dom > (unsigned)(CHS_LOGTAB_N - 1)) sE = __builtin_nan("");  // U left (0,1): the record of this step becomes NaN
-    acc[0] = sE; acc[1] = sEdge; acc[2] = sPS; acc[3] = (double)cSA; acc[4] = s2;
-  }
-  if constexpr (ADAPT) {
-    // Adaptive step (solver.py:177-183): on the steps whose successor re-evaluates delt, the column
-    // sums of delt_max/sqrt(1 + alpha*mu^2) are needed.  mu of the next step is in the registers
-    // right now: every workgroup adds up its rows per column (through the idle exchange scratch) and
-    // writes one partial row; k_colmin sums the partial rows and takes the minimum.  No sweep of U.
-    // NH passes over the columns when a row of doubles does not fit the scratch (fp32 transforms)
-    constexpr int LDSB = C::C * C::SCR * (int)sizeof(T);
-    constexpr int NH = (C::C == 1 || C::N * 8 <= LDSB) ? 1 : 2;
-    constexpr int JH = (C::R0 / 2) / NH;  // quads j*L1 .. (j+1)*L1 cover a quarter (R0 = 8) of the columns each
-    static_assert(!ADAPT || (FUSE && C::C <= 4 && (C::C == 1 || C::N * 8 / NH <= LDSB) && (C::R0 / 2) % NH == 0),
-                  "partial column sums need the scratch");
-    const long long cs = st->computed_steps + 1;  // the record of this step has not advanced it yet
-    if (cs > 500 && (cs % 2) == 0) {              // (uniform) cf. k_mu's want_col
-      const int lg = launder(l);
-      double* prow = partColRows + (size_t)blockIdx.x * C::N;
-      double* gl = reinterpret_cast<double*>(chs_dyn_lds);
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-#pragma unroll
-        for (int s = C::C - 1; s >= 0; --s) {
-          __syncthreads();
-          if (sub == s) {
-#pragma unroll
-            for (int q = 0; q < C::NP0; ++q) {
-              const int m1 = lg + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-              for (int j = h * JH; j < (h + 1) * JH; ++j) {
-                T q1[4], q2[4];
-                unpack_quads<C>(re, im, q, j, q1, q2);  // mu of row `row`, columns 4*(m + L1*j) .. +3
-                const int c1 = 4 * (m1 + C::L1 * j), c2 = 4 * (m2 + C::L1 * j);
-                const int o1 = c1 - h * (C::N / NH), o2 = c2 - h * (C::N / NH);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  double g1 = chs_dt_integrand((double)q1[e], dc.delt_max);
-                  double g2 = chs_dt_integrand((double)q2[e], dc.delt_max);
-                  if (s < C::C - 1) { g1 += gl[o1 + e]; g2 += gl[o2 + e]; }
-                  if (s > 0) { gl[o1 + e] = g1; gl[o2 + e] = g2; }
-                  else { prow[c1 + e] = g1; prow[c2 + e] = g2; }
-                }
-                __builtin_amdgcn_sched_barrier(0);  // one quad pair at a time: no pile-up of addresses and operands
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();  // the scratch goes back to the forward passes
-    }
-  }
-  if constexpr (DIAG && FUSE) STAMP(0, 4);
-  if constexpr (FUSE) {
-    __builtin_amdgcn_sched_barrier(0);
-    fwd_passes<C>(re, im, scr, tbp, launder(l));
-    if constexpr (DIAG && FUSE) STAMP(0, 5);
-    __builtin_amdgcn_sched_barrier(0);
-    // (CHS_ROW_PIPE: twiddles of the next slot ahead of this slot's stores -- measured slower here)
-    recombine<C, true, false, CHS_ROW_PIPE>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
-                              [](int, const int*, T*, bool, NoFetch) {},
-                              [&](int, const int idx[4], T y[4], bool live) {
-      if (live) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) *at_boff(T1, tile_boff<C>(row, idx[t])) = y[t];
-      }
-    });
-  }
-  if constexpr (DIAG && FUSE) STAMP(0, 6);
-  if constexpr (DIAG) {
-    // reductions last: the transform registers are dead by now
-    double out5[5];
-    block_sum_store<5, C::THREADS / 64>(acc, red, out5);
-    if (threadIdx.x == 0) {
-      double* p = partDiag + (size_t)blockIdx.x * 4;
-      p[0] = out5[0]; p[1] = out5[1]; p[2] = out5[2]; p[3] = out5[3];
-      if (FUSE) partMu[blockIdx.x] = out5[4];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_col: one workgroup per column tile (C columns, one group each).
-// The tile (N rows x C columns, contiguous) is staged through LDS in two rounds of
-// N/2 rows so that HBM sees only 16-byte coalesced accesses.
-// MODE_STEP also accumulates sum(hat_U^2 (sin^2(pi kr/N) + sin^2(pi kc/N))) per tile:
-// by Parseval this is the interior part of np.gradient's sum of squares (solver.py:
-// 213-217) -- see DESIGN.md section "E2 from the spectrum".
-// ---------------------------------------------------------------------------
-template <class C>
-struct ColStage {
-  // A workgroup stages C of the CT columns of a tile: per row a piece of C elements at offset
-  // h*C inside the row's CT elements (C == CT: the whole, contiguous tile).
-  static constexpr int LINE = 4 * C::C;        // elements of one staged 4-row line in LDS
-  static constexpr int LP = LINE + 1;          // padded line pitch in LDS (conflict-free quad reads)
-  static constexpr int LINES = C::M / 4;       // lines per round (N/2 rows)
-  static constexpr int ROWS = C::N / 2;        // rows per round
-  static constexpr int ELEMS = LINES * LP;     // staging elements
-  static constexpr int JR = C::R0 / 4;         // pass-0 half-indices j per round
-  static constexpr int PW = (C::C % 2 == 0) ? 2 : 1;            // elements per piece (a 16-byte piece when it can be)
-  static constexpr int PER = ROWS * C::C / (PW * C::THREADS);   // pieces per thread per round
-  static constexpr int Q = C::CT / C::C;       // workgroups per tile
-  static_assert(C::R0 >= 4, "pass-0 radix must be >= 4");
-  static_assert((ROWS * C::C) % (PW * C::THREADS) == 0, "the tile must split evenly over the threads");
-  // global element offset (inside the tile) and LDS offset of piece f = PW*(tid + i*THREADS) of round rho
-  static __device__ __forceinline__ size_t goff(int rho, int f, int h) {
-    const int row = f / C::C, c = f % C::C;
-    return ((size_t)rho * ROWS + row) * C::CT + h * C::C + c;
-  }
-  static __device__ __forceinline__ int loff(int f) {
-    const int row = f / C::C, c = f % C::C;
-    return (row / 4) * LP + (row % 4) * C::C + c;
-  }
-};
-
-// elements of the pass twiddle tables tw0 | twa | twb (contiguous in the table buffer, build_tables)
-template <class C>
-constexpr int col_tw_elems() {
-  return 2 * ((C::R0 - 1) * C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
-}
-
-template <class C>
-constexpr int col_lds_elems() {
-  return (C::C * C::SCR > ColStage<C>::ELEMS) ? C::C * C::SCR : ColStage<C>::ELEMS;
-}
-
-template <class C, int MODE>
-__global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T* __restrict__ Tin, typename C::T* __restrict__ Tout,
-                                                typename C::T* __restrict__ hat, typename C::T* __restrict__ nat,
-                                                FTables<typename C::T> tb, const double* __restrict__ lam,
-                                                const double* __restrict__ sinsq, DevState* __restrict__ st,
-                                                double* __restrict__ partE2, TailArgs ta) {
-  using T = typename C::T;
-  using CS = ColStage<C>;
-  __shared__ double red[32];
-  if (st->halt) return;
-  if constexpr (MODE == MODE_STEP) stagger_start<CHS_STAGGER_COL>();
-  if constexpr (MODE == MODE_STEP) STAMP(1, 0);
-  T* lds = reinterpret_cast<T*>(chs_dyn_lds);
-  int bid = blockIdx.x;
-  if constexpr (MODE == MODE_STEP) {
-    // one extra workgroup, dispatched FIRST (block 0) so that its short chain of dependent loads runs
-    // under the first wave of tiles instead of trailing the kernel: the record of the PREVIOUS step
-    // and this step's time bookkeeping (chs_fast_step), instead of a launch of its own
-    if (ta.enabled) {
-      if (bid == 0) {
-        step_tail_body<C::THREADS>(ta, st, reinterpret_cast<double*>(chs_dyn_lds));
-        return;
-      }
-      bid -= 1;
-    }
-  }
-  // Direct tile access (fp64, two of a tile's four columns per workgroup, groups of whole wavefronts): a
-  // wavefront holds 32 lanes of EACH of the two columns -- lane i the first, lane i+32 the second, same
-  // butterfly index -- so that the 4 rows x 2 columns a pair of lanes needs are four 16-byte pieces of one
-  // 128-byte line: each lane loads two of them and one half-wave swap per register hands the neighbour its
-  // column.  No LDS staging, no staging barriers; HBM still sees 16-byte pieces at a 32-byte pitch, like
-  // the staged path (the other half of every 32 bytes belongs to the sibling workgroup of the tile).
-  constexpr bool DIRECT = (CHS_COL_DIRECT != 0) && sizeof(T) == 8 && C::C == 2 && C::CT == 4 && (C::G % 64 == 0) &&
-                          (CHS_COL_PARK == 0) && (CHS_COL_H0 == 0);
-  int l, sub;
-  if constexpr (DIRECT) {
-    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    sub = ln >> 5;
-    l = w * 32 + (ln & 31);
-  } else {
-    l = threadIdx.x % C::G;
-    sub = threadIdx.x / C::G;
-  }
-  // tile and the part of it this workgroup owns; the Q workgroups of a tile get block numbers
-  // b, b+8, ...: same XCD under round-robin dispatch (speed only, see row_of_block)
-  int ct, hh;
-  if constexpr (CS::Q == 1) {
-    ct = bid; hh = 0;
-  } else {
-    const int xcd = bid & 7, j = bid >> 3;
-    ct = xcd + 8 * (j / CS::Q); hh = j % CS::Q;
-  }
-  if constexpr (MODE == MODE_STEP) {
-    // every other step walks the tiles in the opposite direction: what the previous step touched
-    // last (hat_U of its last tiles, still in the 256 MB Infinity Cache) is touched first
-    if (ta.reverse) ct = C::N / C::CT - 1 - ct;
-  }
-  const int kc = ct * C::CT + hh * C::C + sub;  // this group's column
-  T* scr = lds + (size_t)sub * C::SCR;
-  T re[C::E], im[C::E];
-  // MODE_STEP: the twiddles of the radix passes come from LDS (copied once per workgroup; visible
-  // behind the barriers of the stage-in): no L2 round trip per pass, and no load that would have to
-  // wait behind the hat_U stores at the start of the inverse passes
-  FTables<T> tbp = tb;
-  if constexpr (MODE == MODE_STEP && CHS_COL_TW_LDS) {
-    T* ltw = lds + col_lds_elems<C>() + (CHS_COL_PARK ? C::E * C::THREADS : 0);
-    constexpr int NTW = col_tw_elems<C>();
-    for (int i = 2 * threadIdx.x; i < NTW; i += 2 * C::THREADS) {
-      if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(ltw + i) = *reinterpret_cast<const double2*>(tb.tw0 + i);
-      else *reinterpret_cast<float2*>(ltw + i) = *reinterpret_cast<const float2*>(tb.tw0 + i);
-    }
-    tbp.tw0 = ltw;
-    tbp.twa = ltw + 2 * (C::R0 - 1) * C::L1;
-    tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
-  }
-  T* hcol = hat + (size_t)kc * C::N;
-  // constants of the spectral stage, requested here: their latency disappears behind the stage-in
-  // (loaded where they are used they cost every workgroup ~4 K cycles of waiting)
-  double lam1 = st->lam1, lam2 = st->lam2;  // (gated launches read them again behind the gate)
-  // (the column index is wave-uniform when a group fills whole wavefronts: scalar loads, no VGPRs)
-  const int kc_u = (C::G >= 64 && !DIRECT) ? __builtin_amdgcn_readfirstlane(kc) : kc;
-  const double lc = lam[kc_u];
-  const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc_u + 1] : 0.0;
-  // What the spectral stage reads per recombination slot (4 positions of this lane): {lambda_kr,
-  // sin^2(pi kr/N)} from the table (L2), fetched one slot ahead, and hat_U.  The lane's 2E values of
-  // hat_U are parked in LDS long before they are needed (every lane reads back only what it wrote,
-  // so no barrier guards the parking slots themselves):
-  //   positions 0..E-1   requested with the tile at kernel entry -> hpark1 (its own LDS area)
-  //   positions E..2E-1  requested after the forward passes      -> hpark2 = the exchange scratch,
-  //                      idle until the inverse passes
-  struct Fetched { double2 ls[4]; T h[(CHS_COL_PARK != 0) ? 1 : 4]; };
-  // hat_U of positions 0..3 -- the first slot of every lane and the special lane's own slot --
-  // requested before the forward passes (CHS_COL_H0): nothing waits for it at the start of the stage
-  constexpr bool H0 = (MODE == MODE_STEP) && (CHS_COL_H0 != 0) && (CHS_COL_PARK == 0);
-  T h0[4] = {T(0), T(0), T(0), T(0)};
-  auto fetch = [&](int pbase, const int idx[4]) {
-    Fetched p;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];
-    if constexpr (CHS_COL_PARK == 0) {
-      if (H0 && pbase == 0) {  // (compile-time after inlining)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) p.h[t] = h0[t];
-      } else {
-        const T* hl = hcol + fc_opaque(l);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) p.h[t] = hl[(size_t)(pbase + t) * C::G];
-      }
-    }
-    return p;
-  };
-  constexpr bool PARK = (MODE == MODE_STEP) && (CHS_COL_PARK != 0);
-  T* hpark1 = lds + col_lds_elems<C>() + threadIdx.x;
-  T* hpark2 = lds + threadIdx.x;
-  T hearly[PARK ? C::E : 1];
-  if constexpr (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE) {
-    if constexpr (DIRECT) {
-      // ---- tile rows -> quads, straight from HBM/L2 into the registers of the transform
-      const T* tile = Tin + (size_t)ct * C::N * C::CT + hh * C::C;
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-        for (int j = 0; j < C::R0 / 2; ++j) {
-          // rows 4m .. 4m+3 of the quad: this lane fetches rows 4m + 2 sub and 4m + 2 sub + 1, both columns
-          const T* p1 = tile + (size_t)(4 * (m1 + C::L1 * j) + 2 * sub) * C::CT;
-          const T* p2 = tile + (size_t)(4 * (m2 + C::L1 * j) + 2 * sub) * C::CT;
-          const double2 x1 = *reinterpret_cast<const double2*>(p1), y1 = *reinterpret_cast<const double2*>(p1 + C::CT);
-          const double2 x2 = *reinterpret_cast<const double2*>(p2), y2 = *reinterpret_cast<const double2*>(p2 + C::CT);
-          T q1[4] = {x1.x, y1.x, x1.y, y1.y}, q2[4] = {x2.x, y2.x, x2.y, y2.y};
-          // (x.x, x.y) = (column 0, column 1) of one row: the swap leaves row 4m (+1) of the lane's own column
-          // in .x and row 4m+2 (+3) in .y, in both half-waves
-          swap_halves(q1[0], q1[2]); swap_halves(q1[1], q1[3]);
-          swap_halves(q2[0], q2[2]); swap_halves(q2[1], q2[3]);
-          pack_quads<C>(q1, q2, q, j, re, im);
-        }
-      }
-      __syncthreads();  // (the pass twiddles copied to LDS above are visible from here on)
-    } else {
-    // ---- stage in: tile rows -> quads of this group's column.  The whole tile is requested
-    // first (one HBM latency for both rounds), then it passes through LDS half by half.
-    const T* tile = Tin + (size_t)ct * C::N * C::CT;
-    constexpr int PER = CS::PER;
-    constexpr int PW = CS::PW;
-    T stage[2][PW * PER];
-    auto request = [&](int rho) {
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int f = PW * (threadIdx.x + i * C::THREADS);
-        const T* src = tile + CS::goff(rho, f, hh);
-        if constexpr (PW == 1) {
-          stage[rho][i] = *src;
-        } else if constexpr (sizeof(T) == 8) {
-          const double2 v = *reinterpret_cast<const double2*>(src);
-          stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
-        } else {
-          const float2 v = *reinterpret_cast<const float2*>(src);
-          stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
-        }
-      }
-    };
-    request(0);
-    if constexpr (CHS_COL_PRELOAD == 2) request(1);
-    if constexpr (PARK) {
-#pragma unroll
-      for (int p = 0; p < C::E; ++p) hearly[p] = hcol[(size_t)p * C::G + l];
-    }
-#pragma unroll
-    for (int rho = 0; rho < 2; ++rho) {
-      __syncthreads();
-      if constexpr (CHS_COL_PRELOAD != 2) {
-        if (rho == 1) request(1);
-      }
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int f = PW * (threadIdx.x + i * C::THREADS);
-        const int lo = CS::loff(f);
-        lds[lo] = stage[rho][PW * i];
-        if constexpr (PW == 2) lds[lo + 1] = stage[rho][2 * i + 1];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-        for (int jj = 0; jj < CS::JR; ++jj) {
-          const int j = rho * CS::JR + jj;
-          T q1[4], q2[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            q1[e] = lds[(m1 + C::L1 * jj) * CS::LP + e * C::C + sub];
-            q2[e] = lds[(m2 + C::L1 * jj) * CS::LP + e * C::C + sub];
-          }
-          pack_quads<C>(q1, q2, q, j, re, im);
-        }
-      }
-    }
-    __syncthreads();
-    }
-    if constexpr (MODE == MODE_STEP) STAMP(1, 1);
-    if constexpr (PARK) {
-#pragma unroll
-      for (int p = 0; p < C::E; ++p) hpark1[p * C::THREADS] = hearly[p];
-    }
-    if constexpr (H0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) h0[t] = hcol[(size_t)t * C::G + l];
-    }
-    fwd_passes<C>(re, im, scr, tbp, l);
-    if constexpr (MODE == MODE_STEP) STAMP(1, 2);
-    if constexpr (MODE == MODE_STEP) {
-      // Gated tail: the bookkeeping of the previous step -- stop rules, adaptive time step -- runs as block 0
-      // of THIS launch; nothing has been written yet (staging and forward passes only read), so wait for its
-      // decision here: stopped -> leave hat_U, T and the partial sums as the previous step left them
-      // (run_steps rebuilds U from hat_U); otherwise take this step's coefficients from it.
-      if (ta.gate) {
-        if (gate_wait(st, ta.seq, lam1, lam2)) return;
-      }
-    }
-    if constexpr (PARK) {
-      __syncthreads();  // every wavefront has read its last exchange: the scratch is free
-      T hlate[C::E];
-#pragma unroll
-      for (int p = 0; p < C::E; ++p) hlate[p] = hcol[(size_t)(C::E + p) * C::G + l];
-#pragma unroll
-      for (int p = 0; p < C::E; ++p) hpark2[p * C::THREADS] = hlate[p];
-    }
-  }
-
-  // ---- recombination / spectral stage / adjoint recombination, in place per slot
-  double e2 = 0.0;
-  T h00 = T(0);
-  constexpr bool FWD = (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE);
-  constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL || MODE == MODE_INV_NATIVE);
-  if constexpr (MODE == MODE_STEP) {
-    recombine<C, true, true, CHS_COL_PIPE>(re, im, tb, l, fetch,
-      [&](int pbase, const int*, T y[4], bool live, const Fetched& p) {
-        T hold[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int pos = pbase + t;  // compile-time after unrolling
-          if constexpr (PARK) hold[t] = (pos < C::E) ? hpark1[pos * C::THREADS] : hpark2[(pos - C::E) * C::THREADS];
-          else hold[t] = p.h[t];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const T h = chs_spectral<T>(hold[t], y[t], p.ls[t].x, lc, lam1, lam2);
-          y[t] = h;
-          const double term = (double)h * (double)h * (p.ls[t].y + sqc);
-          e2 += live ? term : 0.0;
-          if (pbase + t == 0 && live) h00 = h;  // lane 0 holds kr = 0 at position 0 (its own slot)
-        }
-        asm volatile("" : "+v"(e2));  // do not postpone the 2E energy terms
-      },
-      [&](int pbase, const int*, T y[4], bool live) {
-        if (live) {
-          T* hl = hcol + fc_opaque(l);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) hl[(size_t)(pbase + t) * C::G] = y[t];
-        }
-      });
-  } else {
-    recombine<C, FWD, ADJ, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
-                           [&](int pbase, const int idx[4], T y[4], bool live, NoFetch) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int kr = idx[t];
-        const size_t hp = (size_t)(pbase + t) * C::G + l;
-        if constexpr (MODE == MODE_FWD_NATIVE) {
-          if (live) hcol[hp] = y[t];
-        } else if constexpr (MODE == MODE_FWD_NATURAL) {
-          if (live) nat[(size_t)kr * C::N + kc] = y[t];
-        } else if constexpr (MODE == MODE_INV_NATIVE) {
-          y[t] = hcol[hp];  // hat_U as MODE_STEP left it: the column half of U = idctn(hat_U)
-        } else {
-          y[t] = nat[(size_t)kr * C::N + kc];
-        }
-      }
-    }, [](int, const int*, T*, bool) {});
-  }
-  if constexpr (MODE == MODE_STEP) STAMP(1, 5);
-  if constexpr (MODE == MODE_STEP) {
-    if (l == 0 && kc == 0) st->meanU = (double)h00 / (double)C::N;  // ortho DC term = sum(U)/N (solver.py:223)
-  }
-  if constexpr (MODE == MODE_STEP) STAMP(1, 3);
-  if constexpr (ADJ) {
-    // wave-local groups exchange behind wavefront fences only: the parked hat_U of another
-    // wavefront may lie in this group's scratch, so everybody must be through the spectral stage
-    if constexpr (PARK && C::WAVE_LOCAL) __syncthreads();
-    inv_passes<C>(re, im, scr, tbp, l);
-    if constexpr (MODE == MODE_STEP) STAMP(1, 4);
-    // ---- stage out: quads -> tile rows
-    if constexpr (DIRECT) {
-      T* tile = Tout + (size_t)ct * C::N * C::CT + hh * C::C;
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int ld = launder(l);
-        const int m1 = ld + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-        for (int j = 0; j < C::R0 / 2; ++j) {
-          T q1[4], q2[4];
-          unpack_quads<C>(re, im, q, j, q1, q2);
-          swap_halves(q1[0], q1[2]); swap_halves(q1[1], q1[3]);   // back to (column 0, column 1) of two rows
-          swap_halves(q2[0], q2[2]); swap_halves(q2[1], q2[3]);
-          T* p1 = tile + (size_t)(4 * (m1 + C::L1 * j) + 2 * sub) * C::CT;
-          T* p2 = tile + (size_t)(4 * (m2 + C::L1 * j) + 2 * sub) * C::CT;
-          *reinterpret_cast<double2*>(p1) = make_double2(q1[0], q1[2]);
-          *reinterpret_cast<double2*>(p1 + C::CT) = make_double2(q1[1], q1[3]);
-          *reinterpret_cast<double2*>(p2) = make_double2(q2[0], q2[2]);
-          *reinterpret_cast<double2*>(p2 + C::CT) = make_double2(q2[1], q2[3]);
-        }
-      }
-    } else {
-    T* tile = Tout + (size_t)ct * C::N * C::CT;
-#pragma unroll
-    for (int rho = 0; rho < 2; ++rho) {
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-        for (int jj = 0; jj < CS::JR; ++jj) {
-          const int j = rho * CS::JR + jj;
-          T q1[4], q2[4];
-          unpack_quads<C>(re, im, q, j, q1, q2);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            lds[(m1 + C::L1 * jj) * CS::LP + e * C::C + sub] = q1[e];
-            lds[(m2 + C::L1 * jj) * CS::LP + e * C::C + sub] = q2[e];
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < CS::PER; ++i) {
-        // laundered: the staging addresses are recomputed here instead of being kept alive in
-        // registers since the stage-in (a spill reload here would wait on every hat_U store)
-        const int f = CS::PW * (launder((int)threadIdx.x) + i * C::THREADS);
-        const int lo = CS::loff(f);
-        T* dst = tile + CS::goff(rho, f, hh);
-        if constexpr (CS::PW == 1) {
-          *dst = lds[lo];
-        } else {
-          const T a = lds[lo], b = lds[lo + 1];
-          if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(a, b);
-          else *reinterpret_cast<float2*>(dst) = make_float2(a, b);
-        }
-      }
-    }
-    }
-  }
-  if constexpr (MODE == MODE_STEP) {
-    // the tile's share of the spectral gradient sum, last (registers are free, one barrier)
-    const double acc1[1] = {e2};
-    double tot1[1];
-    block_sum_store<1, C::THREADS / 64>(acc1, red, tot1);
-    if (threadIdx.x == 0) partE2[bid] = tot1[0];
-  }
-}
-
-// ---------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------
-enum { ROW_INV_PLAIN = 0, ROW_INV_DIAG = 1, ROW_INV_FUSED = 2, ROW_INV_FUSED_ADAPT = 3 };
-
-struct FastPlan {
-  int N, G, R0, RA, RB, RL, threads, col_tiles;
-  void* tables = nullptr;  // one device allocation
-  size_t off_tw0, off_twa, off_twb, off_wp, off_t1, off_t2;  // element offsets
-  int (*row_fwd)(Engine*, const void*, void*, bool) = nullptr;
-  int (*row_fwd2)(Engine*, const void*, void*, void*) = nullptr;
-  int (*row_inv)(Engine*, int, const void*, void*, void*) = nullptr;
-  int (*col)(Engine*, int, const void*, void*, void*, void*) = nullptr;
-  int (*init)(Engine*) = nullptr;
-};
-
-template <typename T>
-static FTables<T> get_tables(Engine* E) {
-  FastPlan* P = (FastPlan*)E->dTw;
-  const T* base = (const T*)P->tables;
-  FTables<T> tb;
-  tb.tw0 = base + P->off_tw0; tb.twa = base + P->off_twa; tb.twb = base + P->off_twb; tb.wp = base + P->off_wp;
-  tb.t1 = base + P->off_t1; tb.t2 = base + P->off_t2;
-  return tb;
-}
-
-template <class C, class CC = C>
-struct Launch {
-  using T = typename C::T;
-  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0) +
-                                    (CHS_ROW_TW_LDS ? (size_t)row_tw_elems<C>() * sizeof(T) : 0) + CHS_ROW_LDS_PAD;
-  // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
-  static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && (C::R0 % 4 == 0);
-  // + the parking area of half a hat_U column per lane (k_col<MODE_STEP>)
-  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (CHS_COL_PARK ? (size_t)CC::E * CC::THREADS : 0) +
-                                     (CHS_COL_TW_LDS ? (size_t)col_tw_elems<CC>() : 0)) * sizeof(T) + CHS_COL_LDS_PAD;
-  static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
-
-  template <class K>
-  static int set_lds(K kernel, size_t bytes) {
-    CHS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return CHS_OK;
-  }
-  static int init(Engine* E) {
-    (void)E;
-    int rc;
-    if ((rc = set_lds(k_row_fwd<C, true>, row_lds))) return rc;
-    if ((rc = set_lds(k_row_fwd<C, false>, row_lds))) return rc;
-    if ((rc = set_lds(k_row_fwd2<C>, row_lds))) return rc;
-    if ((rc = set_lds(k_row_inv<C, false, false>, row_lds))) return rc;
-    if ((rc = set_lds(k_row_inv<C, true, false>, row_lds))) return rc;
-    if ((rc = set_lds(k_row_inv<C, true, true>, row_lds))) return rc;
-    if constexpr (ADAPT_OK) {
-      if ((rc = set_lds(k_row_inv<C, true, true, true>, row_lds))) return rc;
-    }
-    E->fusedAdapt = ADAPT_OK && getenv("CHS_ADAPT_SWEEP") == nullptr;  // CHS_ADAPT_SWEEP=1: keep the separate sweep of U
-    if ((rc = set_lds(k_col<CC, MODE_STEP>, col_lds))) return rc;
-    if ((rc = set_lds(k_col<CC, MODE_FWD_NATIVE>, col_lds))) return rc;
-    if ((rc = set_lds(k_col<CC, MODE_FWD_NATURAL>, col_lds))) return rc;
-    if ((rc = set_lds(k_col<CC, MODE_INV_NATURAL>, col_lds))) return rc;
-    if ((rc = set_lds(k_col<CC, MODE_INV_NATIVE>, col_lds))) return rc;
-    return CHS_OK;
-  }
-  static int row_fwd(Engine* E, const void* in, void* out, bool pointwise) {
-    const int grid = C::N / C::C;
-    if (pointwise)
-      k_row_fwd<C, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
-                                                            E->dPartMu);
-    else
-      k_row_fwd<C, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
-                                                             E->dPartMu);
-    CHS_HIP(hipGetLastError());
-    return CHS_OK;
-  }
-  static int row_fwd2(Engine* E, const void* in, void* ta, void* t1) {
-    k_row_fwd2<C><<<C::N / C::C, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)ta, (T*)t1, get_tables<T>(E), E->dc,
-                                                                E->dState, E->dPartMu);
-    CHS_HIP(hipGetLastError());
-    return CHS_OK;
-  }
-  static int row_inv(Engine* E, int mode, const void* t2, void* u, void* t1) {
-    const int grid = C::N / C::C;
-    const FTables<T> tb = get_tables<T>(E);
-    if (mode == ROW_INV_PLAIN)
-      k_row_inv<C, false, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                    E->dPartDiag, E->dPartMu, E->dPartRa, 1);
-    else if (mode == ROW_INV_DIAG)
-      k_row_inv<C, true, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                   E->dPartDiag, E->dPartMu, E->dPartRa, 1);
-    else if (mode == ROW_INV_FUSED)
-      k_row_inv<C, true, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                  E->dPartDiag, E->dPartMu, E->dPartRa, E->storeU ? 1 : 0);
-    else {
-      if constexpr (ADAPT_OK)
-        k_row_inv<C, true, true, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                          E->dPartDiag, E->dPartMu, E->dPartRa, E->storeU ? 1 : 0, E->dPartColRows);
-      else { chs_set_error("fused adaptive row kernel is not built for this configuration"); return CHS_EINVAL; }
-    }
-    CHS_HIP(hipGetLastError());
-    return CHS_OK;
-  }
-  static int col(Engine* E, int mode, const void* tin, void* tout, void* hat, void* nat) {
-    const int grid = CC::N / CC::C;
-    const FTables<T> tb = get_tables<T>(E);
-    TailArgs ta;
-    switch (mode) {
-      case MODE_STEP: {
-        int g = grid;
-        if (E->tailDeferred) {
-          ta = chs_tail_args(E, E->tailSet, 1);
-          g = grid + 1;
-          if (E->tailGated) { ta.gate = 1; ta.seq = ++E->gateSeq; }
-        } else if (E->preRider) {
-          ta = chs_tail_args(E, -1, 1);
-          ta.pre_only = 1;
-          g = grid + 1;
-        }
-        E->preRider = false;
-        ta.reverse = (CHS_COL_ZIGZAG && (E->stepCount & 1)) ? 1 : 0;
-        ++E->stepCount;
-        k_col<CC, MODE_STEP><<<g, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
-        break;
-      }
-      case MODE_FWD_NATIVE:
-        k_col<CC, MODE_FWD_NATIVE><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
-        break;
-      case MODE_FWD_NATURAL:
-        k_col<CC, MODE_FWD_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
-        break;
-      case MODE_INV_NATIVE:
-        k_col<CC, MODE_INV_NATIVE><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
-        break;
-      default:
-        k_col<CC, MODE_INV_NATURAL><<<grid, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
-        break;
-    }
-    CHS_HIP(hipGetLastError());
-    return CHS_OK;
-  }
-};
-
-// fp64 configurations: <T, N, G, THREADS, R0, RA, RB, RL, pad1, pad2, padL, waves/SIMD>
-// Small grids are bound by one workgroup life per launch (a handful of workgroups, nothing to overlap
-// with): 8 complex values per lane instead of 16 -- radix-4 end passes -- halve the dependent
-// instruction stream of a lane and double the number of workgroups (CHS_SMALL_E8).
-#ifndef CHS_SMALL_E8
-#define CHS_SMALL_E8 1
-#endif
-#if CHS_SMALL_E8
-using F128 = FCfg<double, 128, 8, 256, 4, 4, 1, 4, 1, 0, 1, 2>;
-using F256 = FCfg<double, 256, 16, 256, 4, 8, 1, 4, 1, 0, 1, 2>;
-using F512 = FCfg<double, 512, 32, 256, 4, 4, 4, 4, 1, 1, 1, 2>;
-using F1024 = FCfg<double, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
-#else
-using F128 = FCfg<double, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
-using F256 = FCfg<double, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
-using F512 = FCfg<double, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
-using F1024 = FCfg<double, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
-#endif
-#ifndef CHS_F2048_E8
-#define CHS_F2048_E8 0
-#endif
-#if CHS_F2048_E8
-// two wavefronts per transform, 8 complex values per lane: twice the workgroups (the ensemble size)
-using F2048 = FCfg<double, 2048, 128, 256, 4, 8, 8, 4, 2, 1, 8, 4, 4>;
-using F2048C = FCfg<double, 2048, 128, 256, 4, 8, 8, 4, 2, 1, 8, 2, 4>;
-#else
-using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
-using F2048C = F2048;
-#endif
-// N = 4096: two wavefronts per transform, 16 complex values per lane, four radix passes
-#ifndef CHS_ROW_WPS
-#define CHS_ROW_WPS 4
-#endif
-#ifndef CHS_ROW_THREADS
-#define CHS_ROW_THREADS 256
-#endif
-// row kernels: CHS_ROW_THREADS/128 rows per workgroup, tiles of 4 columns
-#ifndef CHS_ROW_PADL
-#define CHS_ROW_PADL 16
-#endif
-#ifndef CHS_F4096_CT
-#define CHS_F4096_CT 4  // columns per tile of the T layout (8: 64-byte row pieces; measured)
-#endif
-using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, CHS_ROW_PADL, CHS_ROW_WPS, CHS_F4096_CT>;
-// k_col runs best with the full register file of two waves per SIMD (no spills; the compiler
-// uses the room to keep more loads in flight): measured 305 -> 191 us per launch
-#ifndef CHS_COL_WPS
-#define CHS_COL_WPS 2
-#endif
-#ifndef CHS_COL_THREADS
-#define CHS_COL_THREADS 256
-#endif
-// k_col: CHS_COL_THREADS/128 of the 4 columns of a tile per workgroup
-using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS, CHS_F4096_CT>;
-
-// fp32 configurations (BASELINE.json configs[3]: N = 8192 fp32): 32 complex values per lane
-// occupy the same 64 VGPRs as 16 fp64 ones; reductions and the spectral update stay in fp64.
-#ifndef CHS_G8192_WPS
-#define CHS_G8192_WPS 4
-#endif
-#ifndef CHS_G8192C_WPS
-#define CHS_G8192C_WPS 2
-#endif
-// N = 8192 fp32: four wavefronts per transform, 16 complex values per lane, four radix-8 passes
-#ifndef CHS_G8192_THREADS
-#define CHS_G8192_THREADS 512
-#endif
-#ifndef CHS_F32_CT
-#define CHS_F32_CT 8  // columns per tile of the fp32 T layout at N >= 4096: 32-byte row pieces as in fp64 (4: N=8192 23 % slower)
-#endif
-using G8192 = FCfg<float, 8192, 256, CHS_G8192_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT>;
-using G8192C = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
-#ifndef CHS_G4096_THREADS
-#define CHS_G4096_THREADS 256
-#endif
-using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, CHS_F32_CT>;
-using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, CHS_F32_CT>;
-// fp32 below N = 4096: the shapes of the fp64 configurations (groups inside one wavefront)
-using G128 = FCfg<float, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
-using G256 = FCfg<float, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
-using G512 = FCfg<float, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
-#ifndef CHS_F32_CT_SMALL
-#define CHS_F32_CT_SMALL 8  // N = 2048 fp32: 8 columns per tile (32-byte row pieces; +7 % against 4)
-#endif
-using G1024 = FCfg<float, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
-using G2048 = FCfg<float, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2, (CHS_F32_CT_SMALL ? CHS_F32_CT_SMALL : 4)>;
-// fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
-// two rows or two of a tile's four columns per 512-thread workgroup)
-using F8192 = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 4, 4>;
-using F8192C = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 2, 4>;
-
-template <class C, class CC = C>
-static void bind(FastPlan* P) {
-  P->N = C::N; P->G = C::G; P->R0 = C::R0; P->RA = C::RA; P->RB = C::RB; P->RL = C::RL; P->threads = C::THREADS;
-  P->col_tiles = CC::N / CC::C;
-  P->row_fwd = &Launch<C, CC>::row_fwd;
-  P->row_fwd2 = &Launch<C, CC>::row_fwd2;
-  P->row_inv = &Launch<C, CC>::row_inv;
-  P->col = &Launch<C, CC>::col;
-  P->init = &Launch<C, CC>::init;
-}
 
 bool chs_fast_supported(int N, int dtype) {
   (void)dtype;  // both element types: N = 2^k, 128 <= N <= 8192
@@ -1317,28 +82,8 @@ static int build_tables(Engine* E, FastPlan* P) {
 
 int chs_fast_init(Engine* E) {
   FastPlan* P = new FastPlan();
-  if (E->dtype == CHS_F32) {
-    switch (E->N) {
-      case 128: bind<G128>(P); break;
-      case 256: bind<G256>(P); break;
-      case 512: bind<G512>(P); break;
-      case 1024: bind<G1024>(P); break;
-      case 2048: bind<G2048>(P); break;
-      case 4096: bind<G4096, G4096C>(P); break;
-      case 8192: bind<G8192, G8192C>(P); break;
-      default: delete P; chs_set_error("fast engine (fp32): unsupported N"); return CHS_EINVAL;
-    }
-  } else
-  switch (E->N) {
-    case 128: bind<F128>(P); break;
-    case 256: bind<F256>(P); break;
-    case 512: bind<F512>(P); break;
-    case 1024: bind<F1024>(P); break;
-    case 2048: bind<F2048, F2048C>(P); break;
-    case 4096: bind<F4096, F4096C>(P); break;
-    case 8192: bind<F8192, F8192C>(P); break;
-    default: delete P; chs_set_error("fast engine: unsupported N"); return CHS_EINVAL;
-  }
+  const bool ok = (E->dtype == CHS_F32) ? chs_fast_bind_f32(E->N, P) : chs_fast_bind_f64(E->N, P);
+  if (!ok) { delete P; chs_set_error("fast engine: unsupported N"); return CHS_EINVAL; }
   E->dTw = P;
   int rc = (E->dtype == CHS_F32) ? build_tables<float>(E, P) : build_tables<double>(E, P);
   if (rc) return rc;

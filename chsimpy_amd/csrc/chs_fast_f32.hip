@@ -1,0 +1,50 @@
+// chs_fast_f32.hip -- the fp32 configurations of the fast transform engine (see chs_fast_f64.hip).
+#if !defined(CHS_STAMPS) || defined(CHS_FAST_UNITY_INCLUDE)
+#include "chs_fast_kernels.h"
+
+// fp32 configurations (BASELINE.json configs[3]: N = 8192 fp32): 32 complex values per lane
+// occupy the same 64 VGPRs as 16 fp64 ones; reductions and the spectral update stay in fp64.
+#ifndef CHS_G8192_WPS
+#define CHS_G8192_WPS 4
+#endif
+#ifndef CHS_G8192C_WPS
+#define CHS_G8192C_WPS 2
+#endif
+// N = 8192 fp32: four wavefronts per transform, 16 complex values per lane, four radix-8 passes
+#ifndef CHS_G8192_THREADS
+#define CHS_G8192_THREADS 512
+#endif
+#ifndef CHS_F32_CT
+#define CHS_F32_CT 8  // columns per tile of the fp32 T layout at N >= 4096: 32-byte row pieces as in fp64 (4: N=8192 23 % slower)
+#endif
+using G8192 = FCfg<float, 8192, 256, CHS_G8192_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT>;
+using G8192C = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
+#ifndef CHS_G4096_THREADS
+#define CHS_G4096_THREADS 256
+#endif
+using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, CHS_F32_CT>;
+using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, CHS_F32_CT>;
+// fp32 below N = 4096: the shapes of the fp64 configurations (groups inside one wavefront)
+using G128 = FCfg<float, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
+using G256 = FCfg<float, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
+using G512 = FCfg<float, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
+#ifndef CHS_F32_CT_SMALL
+#define CHS_F32_CT_SMALL 8  // N = 2048 fp32: 8 columns per tile (32-byte row pieces; +7 % against 4)
+#endif
+using G1024 = FCfg<float, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
+using G2048 = FCfg<float, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2, (CHS_F32_CT_SMALL ? CHS_F32_CT_SMALL : 4)>;
+
+bool chs_fast_bind_f32(int N, FastPlan* P) {
+  switch (N) {
+    case 128: bind<G128>(P); break;
+    case 256: bind<G256>(P); break;
+    case 512: bind<G512>(P); break;
+    case 1024: bind<G1024>(P); break;
+    case 2048: bind<G2048>(P); break;
+    case 4096: bind<G4096, G4096C>(P); break;
+    case 8192: bind<G8192, G8192C>(P); break;
+    default: return false;
+  }
+  return true;
+}
+#endif

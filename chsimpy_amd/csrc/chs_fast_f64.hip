@@ -1,0 +1,80 @@
+// chs_fast_f64.hip -- the fp64 configurations of the fast transform engine (a translation unit of its own:
+// the kernel instantiations of the two element types compile in parallel).
+#if !defined(CHS_STAMPS) || defined(CHS_FAST_UNITY_INCLUDE)
+#include "chs_fast_kernels.h"
+
+// fp64 configurations: <T, N, G, THREADS, R0, RA, RB, RL, pad1, pad2, padL, waves/SIMD>
+// Small grids are bound by one workgroup life per launch (a handful of workgroups, nothing to overlap
+// with): 8 complex values per lane instead of 16 -- radix-4 end passes -- halve the dependent
+// instruction stream of a lane and double the number of workgroups (CHS_SMALL_E8).
+#ifndef CHS_SMALL_E8
+#define CHS_SMALL_E8 1
+#endif
+#if CHS_SMALL_E8
+using F128 = FCfg<double, 128, 8, 256, 4, 4, 1, 4, 1, 0, 1, 2>;
+using F256 = FCfg<double, 256, 16, 256, 4, 8, 1, 4, 1, 0, 1, 2>;
+using F512 = FCfg<double, 512, 32, 256, 4, 4, 4, 4, 1, 1, 1, 2>;
+using F1024 = FCfg<double, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
+#else
+using F128 = FCfg<double, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
+using F256 = FCfg<double, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
+using F512 = FCfg<double, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
+using F1024 = FCfg<double, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
+#endif
+#ifndef CHS_F2048_E8
+#define CHS_F2048_E8 0
+#endif
+#if CHS_F2048_E8
+// two wavefronts per transform, 8 complex values per lane: twice the workgroups (the ensemble size)
+using F2048 = FCfg<double, 2048, 128, 256, 4, 8, 8, 4, 2, 1, 8, 4, 4>;
+using F2048C = FCfg<double, 2048, 128, 256, 4, 8, 8, 4, 2, 1, 8, 2, 4>;
+#else
+using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
+using F2048C = F2048;
+#endif
+// N = 4096: two wavefronts per transform, 16 complex values per lane, four radix passes
+#ifndef CHS_ROW_WPS
+#define CHS_ROW_WPS 4
+#endif
+#ifndef CHS_ROW_THREADS
+#define CHS_ROW_THREADS 256
+#endif
+// row kernels: CHS_ROW_THREADS/128 rows per workgroup, tiles of 4 columns
+#ifndef CHS_ROW_PADL
+#define CHS_ROW_PADL 16
+#endif
+#ifndef CHS_F4096_CT
+#define CHS_F4096_CT 4  // columns per tile of the T layout (8: 64-byte row pieces; measured)
+#endif
+using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, CHS_ROW_PADL, CHS_ROW_WPS, CHS_F4096_CT>;
+// k_col runs best with the full register file of two waves per SIMD (no spills; the compiler
+// uses the room to keep more loads in flight): measured 305 -> 191 us per launch
+#ifndef CHS_COL_WPS
+#define CHS_COL_WPS 2
+#endif
+#ifndef CHS_COL_THREADS
+#define CHS_COL_THREADS 256
+#endif
+// k_col: CHS_COL_THREADS/128 of the 4 columns of a tile per workgroup
+using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS, CHS_F4096_CT>;
+
+// fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
+// two rows or two of a tile's four columns per 512-thread workgroup)
+using F8192 = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 4, 4>;
+using F8192C = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 2, 4>;
+
+
+bool chs_fast_bind_f64(int N, FastPlan* P) {
+  switch (N) {
+    case 128: bind<F128>(P); break;
+    case 256: bind<F256>(P); break;
+    case 512: bind<F512>(P); break;
+    case 1024: bind<F1024>(P); break;
+    case 2048: bind<F2048, F2048C>(P); break;
+    case 4096: bind<F4096, F4096C>(P); break;
+    case 8192: bind<F8192, F8192C>(P); break;
+    default: return false;
+  }
+  return true;
+}
+#endif
