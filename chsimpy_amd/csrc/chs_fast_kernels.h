@@ -70,10 +70,6 @@ extern "C" int chs_debug_stamps(int which, unsigned long long* out, int n) {
 
 enum { MODE_STEP = 0, MODE_FWD_NATIVE = 1, MODE_FWD_NATURAL = 2, MODE_INV_NATURAL = 3, MODE_INV_NATIVE = 4 };
 
-template <class C>
-__device__ __forceinline__ size_t tile_addr(int r, int k) {
-  return ((size_t)(k / C::CT) * C::N + r) * C::CT + (k % C::CT);
-}
 // Element (r, k) of a tile-major array through a 32-bit BYTE offset from the (uniform) array base: the
 // access becomes `global_load/store v, voffset, s[base]` -- one or two integer instructions per address
 // instead of a 64-bit multiply-add chain.  N*N*sizeof(T) < 2^32 for every configuration (<= 512 MB).
