@@ -240,3 +240,32 @@ def test_uinit_file_import(gpu, tmp_path):
     assert np.allclose(sol.U, o.U, rtol=RTOL, atol=0)
     assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=RTOL, atol=1e-300)
     sim.solver.close()
+
+
+def test_reference_default_configuration_runs_to_its_energy_stop(gpu):
+    """`Parameters()` exactly as chsimpy ships them (parameters.py:24-61: N=512, ntmax=1e6, full_sim=False;
+    only kappa_tilde is passed explicitly) through `Simulator.solve()`: the run ends at the
+    E2 maximum (step 1674) -- same stop step, tau0, t0, record and field as the oracle, and the million-step
+    call returns as soon as the device has stopped."""
+    p = chsimpy_amd.Parameters()
+    p.kappa_tilde, p.no_gui = KAPPA, True
+    assert (p.N, p.ntmax, p.full_sim, p.adaptive_time, p.jitter) == (512, int(1e6), False, False, None)
+    sim = chsimpy_amd.Simulator(p)
+    t0 = time.time()
+    sol = sim.solve()
+    dt = time.time() - t0
+    o = orc.OracleSolver(orc.OracleParams(N=512))
+    o.prepare()
+    o.solve_or_resume()
+    assert sim.solver._engine.engine == 'fast'
+    assert sol.stop_reason == o.stop_reason == 'energy'
+    assert sol.computed_steps == o.computed_steps == 1674 and sol.tau0 == o.tau0 == 1674
+    assert sol.t0 == pytest.approx(o.t0, rel=1e-12)
+    td, to = sol.timedata.data(), o.timedata.data()
+    assert td.shape == to.shape == (1674, 9)
+    assert np.allclose(td, to, rtol=RTOL, atol=1e-300), [relerr(td[:, c], to[:, c]) for c in range(1, 9)]
+    assert np.allclose(sol.U, o.U, rtol=RTOL, atol=0), relerr(sol.U, o.U)
+    log_line(f"reference default run N=512 (energy stop at 1674): U={relerr(sol.U, o.U):.3e} E2={relerr(td[:, 2], to[:, 2]):.3e} "
+             f"GPU wall {dt:.2f} s")
+    assert dt < 10.0
+    sim.solver.close()
