@@ -44,51 +44,49 @@ class ExperimentParams:
         self.A_seed = 85972
 
 
+def _factor_columns(ep):
+    """Two rows of per-run factors (for A0, for A1) from the seeded source: experiment.py:148-162."""
+    lo, hi = ep.jitter_Arellow, ep.jitter_Arelhigh
+    if ep.A_source == 'sobol':
+        from scipy.stats import qmc
+        # the first `runs` points of the 2^ceil(log2 runs) Sobol points, scaled to [lo, hi]
+        pts = qmc.Sobol(d=2, seed=ep.A_seed).random_base2(int(np.ceil(np.log2(ep.runs))))
+        return qmc.scale(pts, lo, hi)[:ep.runs].T
+    return np.random.Generator(np.random.PCG64(ep.A_seed)).uniform(lo, hi, size=(ep.runs, 2)).T
+
+
+def _lay_out(col_A0, col_A1, independent):
+    """Joint layout: run i scales both coefficients; independent: first only A0 varies, then only A1
+    (experiment.py:163-170, 176-186)."""
+    n = len(col_A0)
+    if not independent:
+        return np.column_stack([col_A0, col_A1])
+    table = np.ones((2 * n, 2))
+    table[:n, 0] = col_A0
+    table[n:, 1] = col_A1
+    return table
+
+
 def make_rand_values(ep: ExperimentParams):
-    """(rand_values, A_list, runs): the factor table of experiment.py:148-190."""
-    A_list = None
-    rand_values = None
+    """(rand_values, A_list, number of runs): the factor table of experiment.py:148-190 for the four A sources
+    (uniform, sobol, grid, or a CSV file of absolute (A0, A1) pairs)."""
     if ep.A_source in ('uniform', 'sobol'):
-        if ep.A_source == 'sobol':
-            from scipy.stats import qmc
-            qrng = qmc.Sobol(d=2, seed=ep.A_seed)
-            m = int(np.ceil(np.log2(ep.runs)))
-            rtemp = qrng.random_base2(m)
-            rtemp = qmc.scale(rtemp, ep.jitter_Arellow, ep.jitter_Arelhigh)
-            rtemp = np.transpose(rtemp[:ep.runs])
-        else:
-            rng = np.random.Generator(np.random.PCG64(ep.A_seed))
-            rtemp = rng.uniform(ep.jitter_Arellow, ep.jitter_Arelhigh, size=(ep.runs, 2))
-            rtemp = np.transpose(rtemp)
-        if ep.independent:  # first A0 varies, then A1
-            rand_values = np.ones((2 * ep.runs, 2))
-            rand_values[:ep.runs, 0] = rtemp[0]
-            rand_values[ep.runs:, 1] = rtemp[1]
-        else:
-            rand_values = np.ones((ep.runs, 2))
-            rand_values[:, 0] = rtemp[0]
-            rand_values[:, 1] = rtemp[1]
-    elif ep.A_source == 'grid':
-        nx = int(np.floor(np.sqrt(ep.runs)))
-        ep.runs = nx * nx
-        xvec = np.linspace(ep.jitter_Arellow, ep.jitter_Arelhigh, nx)
+        f0, f1 = _factor_columns(ep)
+        table = _lay_out(f0, f1, ep.independent)
+        limit = 2 * ep.runs if ep.independent else ep.runs
+        return table, None, min(limit, table.shape[0])
+    if ep.A_source == 'grid':
+        side = int(np.floor(np.sqrt(ep.runs)))
+        ep.runs = side * side                         # (the reference rounds the run count down to a square)
+        axis = np.linspace(ep.jitter_Arellow, ep.jitter_Arelhigh, side)
         if ep.independent:
-            rand_values = np.ones((2 * nx, 2))
-            rand_values[:nx, 0] = xvec
-            rand_values[nx:, 1] = xvec
+            table = _lay_out(axis, axis, True)
         else:
-            pts = np.array([[v, w] for v in xvec for w in xvec])
-            rand_values = np.ones((ep.runs, 2))
-            rand_values[:, 0] = pts[:, 0]
-            rand_values[:, 1] = pts[:, 1]
-    else:
-        A_list = utils.csv_import_matrix(ep.A_source)
-    nr_items = rand_values.shape[0] if A_list is None else A_list.shape[0]
-    if ep.independent and ep.A_source in ('sobol', 'uniform'):
-        nr_items = min(2 * ep.runs, nr_items)
-    else:
-        nr_items = min(ep.runs, nr_items)
-    return rand_values, A_list, nr_items
+            g0, g1 = np.meshgrid(axis, axis, indexing='ij')
+            table = np.column_stack([g0.ravel(), g1.ravel()])
+        return table, None, min(ep.runs, table.shape[0])
+    A_list = utils.csv_import_matrix(ep.A_source)
+    return None, A_list, min(ep.runs, A_list.shape[0])
 
 
 def run_params(init_params: Parameters, run_id, rand_values, A_list):

@@ -3,72 +3,78 @@ chunks, then exports.  Behaviour of ``chsimpy/simulator.py:15-87,135-156`` witho
 the matplotlib views (GUI is out of scope): a chunked run hands host snapshots to
 an optional ``on_update(simulator)`` callback instead.
 """
+import itertools
+
 import numpy as np
 
 from . import parameters, solver, utils
 
 
+def chunk_sizes(total, every):
+    """The calls of a chunked run: ``every`` steps at a time, the last one shortened so that the sum is
+    ``total`` (simulator.py:57-81); endless when ``total`` is None (a run bounded by ``time_max`` only)."""
+    if total is None:
+        assert every > 0
+        return itertools.repeat(every)
+    if total <= 0:
+        return iter(())
+    every = min(every, total)
+    assert every > 0
+    whole, rest = divmod(total, every)
+    return itertools.chain(itertools.repeat(every, whole), (rest,) if rest else ())
+
+
 class Simulator:
     def __init__(self, params=None, U_init=None, on_update=None):
-        if params is None:
-            params = parameters.Parameters()
-        self.params = params
-        if U_init is None and params.Uinit_file is not None:
-            U_init = utils.csv_import_matrix(params.Uinit_file)  # simulator.py:21-22
-        self.solver = solver.Solver(params, U_init)
+        self.params = parameters.Parameters() if params is None else params
+        if U_init is None and self.params.Uinit_file is not None:
+            U_init = utils.csv_import_matrix(self.params.Uinit_file)  # simulator.py:21-22
+        self.solver = solver.Solver(self.params, U_init)
         self.steps_total = 0
         self.solution_file_id = None
         self.view = None
         self.on_update = on_update
         if on_update is None:
-            # no target an update could be applied to (simulator.py:33-34)
+            # nothing an update could be shown on (simulator.py:33-34): one call for the whole run
             self.params.update_every = None
 
     def solve(self):
-        self.solution_file_id = utils.get_or_create_file_id(self.params.file_id)
+        p = self.params
+        sol = self.solver.solution
+        self.solution_file_id = utils.get_or_create_file_id(p.file_id)
         if self.steps_total == 0:
             self.solver.prepare()
-        if self.params.update_every is None:
-            return self.solver.solve_or_resume(self.params.ntmax)
-        # chunked driving, simulator.py:56-87
-        part = 0
-        steps_end = self.params.ntmax
-        if self.params.time_max is not None and self.params.time_max > 0:
-            steps_end = utils.get_int_max_value()
-        dsteps = min(steps_end, self.params.update_every)
-        assert (dsteps > 0)
-        sol = self.solver.solution
-        while ((self.steps_total + dsteps) <= steps_end
-               and (sol.stop_reason == 'None' or self.params.full_sim is True)
-               and (sol.stop_reason != 'time-limit')):
-            self.solver.solve_or_resume(dsteps)
+        if p.update_every is None:
+            return self.solver.solve_or_resume(p.ntmax)
+        # chunked driving (simulator.py:56-87).  The device keeps the field between the chunks; a chunk costs one
+        # call of the C ABI, and the field is downloaded only if on_update looks at it.
+        timed = p.time_max is not None and p.time_max > 0   # then only the time limit ends the run (simulator.py:58-59)
+        for n in chunk_sizes(None if timed else p.ntmax - self.steps_total, p.update_every):
+            stopped = sol.stop_reason == 'time-limit' or (sol.stop_reason != 'None' and p.full_sim is not True)
+            if stopped:
+                break
+            self.solver.solve_or_resume(n)
             self.on_update(self)
-            self.steps_total += dsteps
-            part += 1
-            diff = steps_end - self.steps_total
-            if 0 < diff < dsteps:
-                dsteps = diff
-            elif diff < 0:
-                raise Exception("Something went wrong.")
-        if sol.tau0 == 0:
+            self.steps_total += n
+        if sol.tau0 == 0:   # the energy rule never fired: the reference reports the last step (simulator.py:84-86)
             sol.tau0 = sol.computed_steps - 1
             sol.t0 = self.solver.time_passed
         return sol
 
     def export(self):
-        """CSV export, simulator.py:135-156: ``<file_id>.solution.<member>.csv[.bz2]``."""
-        fname_sol = f"{self.solution_file_id}.solution"
-        solution = self.solver.solution
-        export_csv = self.params.export_csv
-        if export_csv is not None:
-            fext = 'csv.bz2' if self.params.compress_csv else 'csv'
-            for member in export_csv.replace(' ', '').split(','):
-                varray = None
-                if hasattr(solution, member):
-                    varray = getattr(solution, member)
-                if isinstance(varray, np.ndarray):
-                    utils.csv_export_matrix(varray, fname=f"{fname_sol}.{member}.{fext}")
-        return fname_sol
+        """CSV export of the solution members named in ``export_csv`` as
+        ``<file_id>.solution.<member>.csv[.bz2]`` (simulator.py:135-156)."""
+        base = f"{self.solution_file_id}.solution"
+        wanted = self.params.export_csv
+        if wanted is None:
+            return base
+        ext = 'csv.bz2' if self.params.compress_csv else 'csv'
+        sol = self.solver.solution
+        for name in (m for m in wanted.replace(' ', '').split(',') if m):
+            value = getattr(sol, name, None)
+            if isinstance(value, np.ndarray):
+                utils.csv_export_matrix(value, fname=f"{base}.{name}.{ext}")
+        return base
 
     def render(self):
         return None  # views are out of scope
