@@ -644,17 +644,31 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
       };
       const int kk0 = kk_of(0);
       SlotTw<T> wn;
-      const int id0[4] = {kk0, N - kk0, M - kk0, M + kk0};
+      // PIPE: the request for slot 0 of the loop below also serves the special lane's own slot.  That lane's
+      // slot 0 is dead, so ITS share of the request is made for the own slot's indices (0, M/2, M, 3M/2 and the
+      // twiddles of kk = 0) instead: one round trip for the wavefront instead of two in a row (the own slot
+      // used to fetch on its own, with nothing to overlap the wait).
+      const int o1 = PIPE ? (sp ? 0 : kk0) : kk0, o2 = PIPE ? (sp ? M / 2 : N - kk0) : N - kk0;
+      const int o3 = PIPE ? (sp ? M : M - kk0) : M - kk0, o4 = PIPE ? (sp ? 3 * (M / 2) : M + kk0) : M + kk0;
+      const int id0[4] = {o1, o2, o3, o4};
       decltype(pre(0, id0)) pn;
+      SlotTw<T> whp = SlotTw<T>();
       if constexpr (PIPE) {  // slot 0 of the loop below, requested ahead of the special lane's own slot
-        wn = slot_tw<T>(tb, kk0);
+        wn = slot_tw<T>(tb, o1);
         pn = pre(q * R2 * 4, id0);
+        if (sp) whp = slot_tw<T>(tb, M / 2);  // the special lane's second self-paired butterfly
       }
       CHS_RSTAMP(0);
       if (sp) {
-        const SlotTw<T> w0 = slot_tw<T>(tb, 0), wh = slot_tw<T>(tb, M / 2);
         const int idx[4] = {0, M / 2, M, 3 * (M / 2)};
-        const auto p0 = pre(q * R2 * 4, idx);
+        SlotTw<T> w0, wh;
+        decltype(pre(0, id0)) p0;
+        if constexpr (PIPE) {
+          w0 = wn; wh = whp; p0 = pn;
+        } else {
+          w0 = slot_tw<T>(tb, 0); wh = slot_tw<T>(tb, M / 2);
+          p0 = pre(q * R2 * 4, idx);
+        }
         T y[4] = {T(0), T(0), T(0), T(0)};
         if constexpr (FWD) {
           T a0, a1, a2, a3, b0, b1, b2, b3;
@@ -725,6 +739,7 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
           }
         }
       }
+      CHS_RSTAMP(4);
     }
   }
 }

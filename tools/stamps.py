@@ -38,7 +38,8 @@ for which, nblk in ((0, 2048), (1, 2048)):
         okk = (r[:, 0] > 0) & (st[:, 2] > 0)
         print('   wave 0 inside the recombination: fwd done -> enter', int(np.median(r[okk, 0] - st[okk, 2])),
               '| special slot', int(np.median(r[okk, 1] - r[okk, 0])), '| slot 0', int(np.median(r[okk, 2] - r[okk, 1])),
-              '| slots 1-3', int(np.median(r[okk, 3] - r[okk, 2])), '| slots 4-7', int(np.median(st[okk, 5] - r[okk, 3])))
+              '| slots 1-3', int(np.median(r[okk, 3] - r[okk, 2])), '| slots 4-7', int(np.median(st[okk, 10] - r[okk, 3])),
+              '| end of the slots -> past the join (wait for the hat_U stores)', int(np.median(st[okk, 3] - st[okk, 10])))
     d = np.diff(st[:, :n + 1], axis=1)
     ok = np.all(d >= 0, axis=1) & (st[:, 0] > 0)
     d = d[ok]
