@@ -183,7 +183,7 @@ __device__ __forceinline__ void stagger_start() {
 #define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
 #endif
 #ifndef CHS_COL_PRELOAD
-#define CHS_COL_PRELOAD 1  // 2: request the whole tile before staging it; 1: half by half (fewer registers, ~1 % faster)
+#define CHS_COL_PRELOAD 3  // 3: the second half of the tile is requested behind the first half's LDS writes (its latency runs under the first half's quad reads); 1: at the start of the second round; 2: the whole tile up front (more registers)
 #endif
 #ifndef CHS_COL_LDS_PAD
 #define CHS_COL_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower k_col's occupancy
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
       __syncthreads();
-      if constexpr (CHS_COL_PRELOAD != 2) {
+      if constexpr (CHS_COL_PRELOAD == 1) {
         if (rho == 1) request(1);
       }
 #pragma unroll
@@ -826,6 +826,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         const int lo = CS::loff(f);
         lds[lo] = stage[rho][PW * i];
         if constexpr (PW == 2) lds[lo + 1] = stage[rho][2 * i + 1];
+      }
+      if constexpr (CHS_COL_PRELOAD == 3) {
+        // the second half is requested as soon as the first has left its registers: its latency runs under
+        // the first half's barrier and quad reads instead of in front of the second half's LDS writes
+        if (rho == 0) request(1);
       }
       __syncthreads();
 #pragma unroll
