@@ -46,7 +46,16 @@ using F2048C = F2048;
 #ifndef CHS_F4096_CT
 #define CHS_F4096_CT 4  // columns per tile of the T layout (8: 64-byte row pieces; measured)
 #endif
-using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, CHS_ROW_PADL, CHS_ROW_WPS, CHS_F4096_CT>;
+#ifndef CHS_PAD1
+#define CHS_PAD1 2
+#endif
+#ifndef CHS_PAD2
+#define CHS_PAD2 1
+#endif
+#ifndef CHS_COL_PADL
+#define CHS_COL_PADL 16
+#endif
+using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, CHS_PAD1, CHS_PAD2, CHS_ROW_PADL, CHS_ROW_WPS, CHS_F4096_CT>;
 // k_col runs best with the full register file of two waves per SIMD (no spills; the compiler
 // uses the room to keep more loads in flight): measured 305 -> 191 us per launch
 #ifndef CHS_COL_WPS
@@ -56,7 +65,7 @@ using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, 2, 1, CHS_ROW
 #define CHS_COL_THREADS 256
 #endif
 // k_col: CHS_COL_THREADS/128 of the 4 columns of a tile per workgroup
-using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, 2, 1, 16, CHS_COL_WPS, CHS_F4096_CT>;
+using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, CHS_PAD1, CHS_PAD2, CHS_COL_PADL, CHS_COL_WPS, CHS_F4096_CT>;
 
 // fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
 // two rows or two of a tile's four columns per 512-thread workgroup)
