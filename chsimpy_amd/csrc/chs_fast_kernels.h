@@ -262,12 +262,30 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
     }
   }
   if constexpr (POINTWISE) {
-#pragma unroll
-    for (int e = 0; e < C::E; ++e) {
-      re[e] = chs_mu<T>(re[e], RT, BRT, A0, A1);
-      im[e] = chs_mu<T>(im[e], RT, BRT, A0, A1);
-      s2 += (double)re[e] * (double)re[e] + (double)im[e] * (double)im[e];
+    // EnergieEut in the shared-log form of the fused row kernel (log U - log(1-U) from the table-driven log:
+    // no division, no spills at four waves per SIMD; the division-based chs_mu needed 204 bytes of scratch here)
+    double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
+    if constexpr (CHS_LOG_TABLE && sizeof(T) == 8) {
+      for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
+      __syncthreads();
     }
+    unsigned dom = 0;
+    auto mu = [&](T& u) {
+      T m;
+      if constexpr (CHS_LOG_TABLE) {
+        const T uinv = T(1) - u;
+        const T lU = chs_log_unit_tab<T>(u, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
+        m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
+      } else {
+        m = chs_mu<T>(u, RT, BRT, A0, A1);
+      }
+      s2 += (double)m * (double)m;
+      u = m;
+      asm volatile("" : "+v"(u), "+v"(s2), "+v"(dom));  // one grid point at a time (register pressure)
+    };
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) { mu(re[e]); mu(im[e]); }
+    if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of this step becomes NaN
   }
   fwd_passes<C>(re, im, scr, tb, l);
   recombine<C, true, false, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
