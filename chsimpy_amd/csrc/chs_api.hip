@@ -289,8 +289,8 @@ static int one_step(Engine* E, bool first, bool last) {
     if ((rc = chs_fast_step_unfused(E))) return rc;
   }
   if (jitter) {                                    // 210-211
+    // the perturbation and the mean of the perturbed field (meanU, for PS) in one sweep
     if ((rc = E->jitterPcg ? chs_launch_jitter_pcg(E) : chs_launch_jitter(E))) return rc;
-    if ((rc = chs_launch_sum(E, 0))) return rc;
   }
   if ((rc = chs_launch_diag(E, 0))) return rc;     // 213-228
   if ((rc = chs_launch_fin(E, 0))) return rc;      // 230-249

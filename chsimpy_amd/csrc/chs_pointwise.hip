@@ -16,6 +16,7 @@
 #define DISPATCH_T(E, expr_d, expr_f) \
   do { if ((E)->dtype == CHS_F64) { expr_d; } else { expr_f; } } while (0)
 #define PW_BAND 8  // rows per block in the banded sweeps
+#define DIAG_BAND 32  // rows per block in k_diag (blocks of DIAG_BAND x PW_THREADS points)
 
 // ---------------------------------------------------------------------------
 // k_mu: MU = EnergieEut(U); per-band sum(mu^2); per-band column sums of the
@@ -173,43 +174,59 @@ __global__ __launch_bounds__(PW_THREADS) void k_diag(const T* __restrict__ U, De
                                                      const DevState* __restrict__ st,
                                                      double* __restrict__ partDiag, int ignore_halt) {
   __shared__ double scratch[32];
+  __shared__ double2 ltab[CHS_LOGTAB_N];
   if (!ignore_halt && st->halt) return;
+  if constexpr (sizeof(T) == 8) {
+    for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += PW_THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
+    __syncthreads();
+  }
   const int N = dc.N;
-  const int r0 = blockIdx.x * PW_BAND, r1 = min(r0 + PW_BAND, N);
+  // a block = DIAG_BAND rows x PW_THREADS columns; a thread walks down its column with the three vertical
+  // neighbours in registers
+  const int r0 = blockIdx.x * DIAG_BAND, r1 = min(r0 + DIAG_BAND, N);
+  const int c = blockIdx.y * PW_THREADS + threadIdx.x;
   const double mean = st->meanU;
   const double inv2dx = 1.0 / (2.0 * dc.delx), invdx = 1.0 / dc.delx;
   const T RT = (T)dc.RT, B = (T)dc.B, A0 = (T)dc.A0, A1 = (T)dc.A1;
   double sE = 0.0, sG = 0.0, sPS = 0.0, cSA = 0.0;
-  for (int c = threadIdx.x; c < N; c += PW_THREADS) {
+  unsigned dom = 0;
+  if (c < N) {
+    const T* col = U + c;
+    T up = r0 > 0 ? col[(size_t)(r0 - 1) * N] : T(0), cur = col[(size_t)r0 * N];
     for (int r = r0; r < r1; ++r) {
-      const size_t o = (size_t)r * N + c;
-      const T u = U[o];
-      const double ud = (double)u;
+      const size_t o = (size_t)r * N;
+      const T nxt = r < N - 1 ? col[o + N] : T(0);
+      const T lft = c > 0 ? col[o - 1] : T(0), rgt = c < N - 1 ? col[o + 1] : T(0);
+      const double ud = (double)cur;
       double gx, gy;
       if (r == 0)
-        gx = ((double)U[o + N] - ud) * invdx;
+        gx = ((double)nxt - ud) * invdx;
       else if (r == N - 1)
-        gx = (ud - (double)U[o - N]) * invdx;
+        gx = (ud - (double)up) * invdx;
       else
-        gx = ((double)U[o + N] - (double)U[o - N]) * inv2dx;
+        gx = ((double)nxt - (double)up) * inv2dx;
       if (c == 0)
-        gy = ((double)U[o + 1] - ud) * invdx;
+        gy = ((double)rgt - ud) * invdx;
       else if (c == N - 1)
-        gy = (ud - (double)U[o - 1]) * invdx;
+        gy = (ud - (double)lft) * invdx;
       else
-        gy = ((double)U[o + 1] - (double)U[o - 1]) * inv2dx;
+        gy = ((double)rgt - (double)lft) * inv2dx;
       sG += gx * gx + gy * gy;
-      sE += (double)chs_energy_density<T>(u, RT, B, A0, A1);
+      const T uinv = T(1) - cur;
+      const T lU = chs_log_unit_tab<T>(cur, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
+      sE += (double)chs_energy_from_logs<T>(cur, uinv, lU, lV, RT, B, A0, A1);
       sPS += fabs(ud - mean);
       cSA += (ud < dc.threshold) ? 1.0 : 0.0;
+      up = cur; cur = nxt;
     }
   }
+  if (dom > (unsigned)(CHS_LOGTAB_N - 1)) sE = __builtin_nan("");  // U left (0,1): the logarithms are undefined
   const double tE = block_sum(sE, scratch);
   const double tG = block_sum(sG, scratch);
   const double tP = block_sum(sPS, scratch);
   const double tS = block_sum(cSA, scratch);
   if (threadIdx.x == 0) {
-    double* p = partDiag + (size_t)blockIdx.x * 4;
+    double* p = partDiag + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
     p[0] = tE; p[1] = tG; p[2] = tP; p[3] = tS;
   }
 }
@@ -338,12 +355,19 @@ int chs_launch_step_tail(Engine* E, int do_pre) {
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(PW_THREADS) void k_jitter(T* __restrict__ U, const T* __restrict__ noise, double jitter,
-                                                       size_t total, const DevState* __restrict__ st) {
+                                                       size_t total, const DevState* __restrict__ st,
+                                                       double* __restrict__ partSum) {
+  __shared__ double scratch[32];
   if (st->halt) return;
+  double sum = 0.0;  // of the perturbed field, for meanU: same grid and element order as k_jitter_pcg
   for (size_t i = (size_t)blockIdx.x * PW_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * PW_THREADS) {
 #pragma clang fp contract(off)
-    U[i] = (T)((double)U[i] + jitter * (2.0 * (double)noise[i] - 1.0));
+    const T u = (T)((double)U[i] + jitter * (2.0 * (double)noise[i] - 1.0));
+    U[i] = u;
+    sum += (double)u;
   }
+  sum = block_sum(sum, scratch);
+  if (threadIdx.x == 0) partSum[blockIdx.x] = sum;
 }
 
 // ---------------------------------------------------------------------------
@@ -354,6 +378,7 @@ __global__ __launch_bounds__(PW_THREADS) void k_jitter(T* __restrict__ U, const 
 // with the precomputed jump (multTT, plusTT).
 // ---------------------------------------------------------------------------
 typedef unsigned __int128 chs_u128;
+#define CHS_JITTER_BLOCKS_MAX 4096
 #define CHS_PCG_MULT ((((chs_u128)0x2360ED051FC65DA4ULL) << 64) | (chs_u128)0x4385DF649FCCF645ULL)
 __host__ __device__ inline void chs_pcg_jump(chs_u128 delta, chs_u128 inc, chs_u128& acc_mult, chs_u128& acc_plus) {
   chs_u128 cur_mult = CHS_PCG_MULT, cur_plus = inc;
@@ -371,8 +396,11 @@ __global__ __launch_bounds__(PW_THREADS) void k_jitter_pcg(T* __restrict__ U, do
                                                            unsigned long long i_hi, unsigned long long i_lo,
                                                            unsigned long long m_hi, unsigned long long m_lo,
                                                            unsigned long long p_hi, unsigned long long p_lo,
-                                                           const DevState* __restrict__ st) {
+                                                           const DevState* __restrict__ st,
+                                                           double* __restrict__ partSum) {
+  __shared__ double scratch[32];
   if (!INIT && st->halt) return;
+  double sum = 0.0;
   const size_t tt = (size_t)gridDim.x * PW_THREADS, t = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
   const chs_u128 inc = ((chs_u128)i_hi << 64) | i_lo;
   const chs_u128 multTT = ((chs_u128)m_hi << 64) | m_lo, plusTT = ((chs_u128)p_hi << 64) | p_lo;
@@ -388,17 +416,29 @@ __global__ __launch_bounds__(PW_THREADS) void k_jitter_pcg(T* __restrict__ U, do
     {
 #pragma clang fp contract(off)
       if constexpr (INIT) U[i] = (T)(base + jitter * (r - 0.5));  // solver.py:82 (jitter = the scale here)
-      else U[i] = (T)((double)U[i] + jitter * (2.0 * r - 1.0));
+      else {
+        const T u = (T)((double)U[i] + jitter * (2.0 * r - 1.0));
+        U[i] = u;
+        sum += (double)u;
+      }
     }
     s = s * multTT + plusTT;
   }
+  if constexpr (!INIT) {  // the mean of the perturbed field rides along (k_sum_fin finishes it)
+    sum = block_sum(sum, scratch);
+    if (threadIdx.x == 0) partSum[blockIdx.x] = sum;
+  }
+}
+
+// One launch shape for both noise sources, so that their partial sums (and with them meanU and PS) agree bit for bit.
+static int jitter_blocks(size_t total) {
+  int blocks = (int)((total + PW_THREADS * 64 - 1) / ((size_t)PW_THREADS * 64));  // 64 elements per thread
+  return blocks < 1 ? 1 : blocks > CHS_JITTER_BLOCKS_MAX ? CHS_JITTER_BLOCKS_MAX : blocks;
 }
 
 static int launch_pcg(Engine* E, bool init, double a, double base, const unsigned long long st[2], const unsigned long long ic[2]) {
   const size_t total = (size_t)E->N * E->N;
-  int blocks = (int)((total + PW_THREADS * 64 - 1) / ((size_t)PW_THREADS * 64));  // 64 draws per thread
-  if (blocks < 1) blocks = 1;
-  if (blocks > 4096) blocks = 4096;
+  const int blocks = jitter_blocks(total);
   const chs_u128 inc = ((chs_u128)ic[0] << 64) | ic[1];
   chs_u128 mtt, ptt;
   chs_pcg_jump((chs_u128)blocks * PW_THREADS, inc, mtt, ptt);
@@ -407,13 +447,14 @@ static int launch_pcg(Engine* E, bool init, double a, double base, const unsigne
   chs_slot_begin(E, SLOT_MISC);
   if (init) {
     DISPATCH_T(E,
-      (k_jitter_pcg<double, true><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState)),
-      (k_jitter_pcg<float, true><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState)));
+      (k_jitter_pcg<double, true><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState, E->dPartSum)),
+      (k_jitter_pcg<float, true><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState, E->dPartSum)));
   } else {
     DISPATCH_T(E,
-      (k_jitter_pcg<double, false><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState)),
-      (k_jitter_pcg<float, false><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState)));
+      (k_jitter_pcg<double, false><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState, E->dPartSum)),
+      (k_jitter_pcg<float, false><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, a, base, total, st[0], st[1], ic[0], ic[1], mh, ml, ph, pl, E->dState, E->dPartSum)));
   }
+  if (!init) k_sum_fin<<<1, PW_THREADS, 0, E->stream>>>(E->dPartSum, blocks, E->N, E->dState, 0);
   chs_slot_end(E, SLOT_MISC);
   CHS_HIP(hipGetLastError());
   return CHS_OK;
@@ -444,12 +485,12 @@ int chs_pointwise_alloc(Engine* E) {
   const int N = E->N;
   E->nBands = (N + PW_BAND - 1) / PW_BAND;
   E->nPartMu = E->nBands;
-  E->nDiagBlocks = E->nBands;
+  E->nDiagBlocks = ((N + DIAG_BAND - 1) / DIAG_BAND) * ((N + PW_THREADS - 1) / PW_THREADS);
   E->nColMinBlocks = (N + PW_THREADS - 1) / PW_THREADS;
   CHS_HIP(hipMalloc(&E->dPartMu, sizeof(double) * (size_t)(E->nBands > N ? E->nBands : N)));
   CHS_HIP(hipMalloc(&E->dPartMuAux, sizeof(double) * (size_t)E->nBands));
   CHS_HIP(hipMalloc(&E->dPartDiag, sizeof(double) * 4 * (size_t)(E->nDiagBlocks > N ? E->nDiagBlocks : N)));
-  CHS_HIP(hipMalloc(&E->dPartSum, sizeof(double) * (size_t)E->nBands));
+  CHS_HIP(hipMalloc(&E->dPartSum, sizeof(double) * (size_t)(E->nBands > CHS_JITTER_BLOCKS_MAX ? E->nBands : CHS_JITTER_BLOCKS_MAX)));
   CHS_HIP(hipMalloc(&E->dPartColMin, sizeof(double) * (size_t)((N + 31) / 32)));  // k_colmin: N/256 entries, k_colmin_rows: N/32
   CHS_HIP(hipMalloc(&E->dPartCol, sizeof(double) * (size_t)E->nBands * N));
   return CHS_OK;
@@ -566,11 +607,12 @@ int chs_launch_sum(Engine* E, int ignore_halt) {
 }
 
 int chs_launch_diag(Engine* E, int ignore_halt) {
+  const dim3 grid((E->N + DIAG_BAND - 1) / DIAG_BAND, (E->N + PW_THREADS - 1) / PW_THREADS);
   chs_slot_begin(E, SLOT_DIAG);
   DISPATCH_T(E,
-    (k_diag<double><<<E->nDiagBlocks, PW_THREADS, 0, E->stream>>>((const double*)E->dU, E->dc, E->dState,
+    (k_diag<double><<<grid, PW_THREADS, 0, E->stream>>>((const double*)E->dU, E->dc, E->dState,
                                                                    E->dPartDiag, ignore_halt)),
-    (k_diag<float><<<E->nDiagBlocks, PW_THREADS, 0, E->stream>>>((const float*)E->dU, E->dc, E->dState,
+    (k_diag<float><<<grid, PW_THREADS, 0, E->stream>>>((const float*)E->dU, E->dc, E->dState,
                                                                   E->dPartDiag, ignore_halt)));
   chs_slot_end(E, SLOT_DIAG);
   CHS_HIP(hipGetLastError());
@@ -593,14 +635,14 @@ int chs_launch_fin(Engine* E, int prepare_mode, int fused) {
 
 int chs_launch_jitter(Engine* E) {
   const size_t total = (size_t)E->N * E->N;
-  int blocks = (int)((total + PW_THREADS - 1) / PW_THREADS);
-  if (blocks > 4096) blocks = 4096;
+  const int blocks = jitter_blocks(total);
   chs_slot_begin(E, SLOT_MISC);
   DISPATCH_T(E,
     (k_jitter<double><<<blocks, PW_THREADS, 0, E->stream>>>((double*)E->dU, (const double*)E->dNoise, E->jitter, total,
-                                                             E->dState)),
+                                                             E->dState, E->dPartSum)),
     (k_jitter<float><<<blocks, PW_THREADS, 0, E->stream>>>((float*)E->dU, (const float*)E->dNoise, E->jitter, total,
-                                                            E->dState)));
+                                                            E->dState, E->dPartSum)));
+  k_sum_fin<<<1, PW_THREADS, 0, E->stream>>>(E->dPartSum, blocks, E->N, E->dState, 0);
   chs_slot_end(E, SLOT_MISC);
   CHS_HIP(hipGetLastError());
   return CHS_OK;
