@@ -196,6 +196,7 @@ static int download(Engine* E, double* dst, const void* src) {
 extern "C" int chs_set_U(chs_handle h, const double* host_U) {
   Engine* E = (Engine*)h;
   if (!E || !host_U) { chs_set_error("chs_set_U: null argument"); return CHS_EINVAL; }
+  E->resident = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   CHS_HIP(hipStreamSynchronize(E->stream));
   int rc = upload(E, E->dU, host_U);
@@ -229,6 +230,7 @@ extern "C" int chs_get_state(chs_handle h, chs_state* out) {
 extern "C" int chs_set_state(chs_handle h, const chs_state* in) {
   Engine* E = (Engine*)h;
   if (!E || !in) { chs_set_error("chs_set_state: null argument"); return CHS_EINVAL; }
+  E->resident = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   CHS_HIP(hipStreamSynchronize(E->stream));
   DevState s;
@@ -246,6 +248,7 @@ extern "C" int chs_prepare(chs_handle h, double row0[9]) {
   Engine* E = (Engine*)h;
   if (!E || !row0) { chs_set_error("chs_prepare: null argument"); return CHS_EINVAL; }
   if (!E->have_U) { chs_set_error("chs_prepare: chs_set_U first"); return CHS_ESTATE; }
+  E->resident = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   int rc;
   if ((rc = chs_launch_sum(E, 1))) return rc;
@@ -336,7 +339,16 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   if ((rc = chs_launch_call_begin(E))) return rc;
   const bool fused = (E->engine == CHS_ENGINE_FAST) && !((E->dNoise || E->jitterPcg) && E->jitter > 0.0 && E->jitter < 0.1);
   const bool derive = !((flags & CHS_STEP_CARRY_HAT) && E->hat_valid);
-  if (derive && fused && nsteps > 0) {
+  // Fixed time step on the fused pipeline: the last step of a call leaves hat_U, the row transform of
+  // EnergieEut(U) and its sum of squares on the device, and a call that finds them continues the loop where it
+  // stopped -- hat_U is the array the reference would recompute as dctn(idctn(hat_U)) (solver.py:159), equal up
+  // to rounding; CHS_STEP_REDERIVE_HAT asks for the literal recomputation.
+  E->keepResident = fused && !E->dc.adaptive_time && !profile && !(flags & CHS_STEP_LAST_CALL);
+  const bool cont = fused && E->resident && E->hat_valid && !(flags & CHS_STEP_REDERIVE_HAT) && !profile;
+  if (nsteps > 0) E->resident = false;
+  if (cont && nsteps > 0) {
+    // nothing to do: T1, partMu and hat_U are in place
+  } else if (derive && fused && nsteps > 0) {
     // hat_U = dctn(U) and the first step's row transform of EnergieEut(U) from one sweep of U
     if ((rc = chs_fast_enter_fused(E))) return rc;
     E->hat_valid = true;
@@ -402,6 +414,7 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
     CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
   }
   if (s.halt) E->hat_valid = false;  // (a deferred tail lets k_col run once past a NaN stop)
+  if (nsteps > 0) E->resident = E->keepResident && !s.halt && s.rows_written >= nsteps;
   int64_t done = s.rows_written;
   if (done > nsteps) done = nsteps;
   if (steps_done) *steps_done = done;
@@ -457,6 +470,7 @@ extern "C" const char* chs_kernel_name(chs_handle h, int slot) {
 extern "C" int chs_init_U_pcg64(chs_handle h, double base, double scale, const uint64_t state[2], const uint64_t inc[2]) {
   Engine* E = (Engine*)h;
   if (!E || !state || !inc) { chs_set_error("chs_init_U_pcg64: null argument"); return CHS_EINVAL; }
+  E->resident = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   const unsigned long long st[2] = {state[0], state[1]}, ic[2] = {inc[0], inc[1]};
   const int rc = chs_launch_init_pcg(E, base, scale, st, ic);
@@ -497,6 +511,7 @@ extern "C" int chs_set_jitter_noise(chs_handle h, double jitter, const double* h
 extern "C" int chs_dctn(chs_handle h, const double* host_in, double* host_out, int inverse) {
   Engine* E = (Engine*)h;
   if (!E || !host_in || !host_out) { chs_set_error("chs_dctn: null argument"); return CHS_EINVAL; }
+  E->resident = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   CHS_HIP(hipStreamSynchronize(E->stream));
   // dMU/dT2 are scratch between steps
@@ -521,6 +536,7 @@ extern "C" int chs_get_mu(chs_handle h, double* host_mu) {
   Engine* E = (Engine*)h;
   if (!E || !host_mu) { chs_set_error("chs_get_mu: null argument"); return CHS_EINVAL; }
   if (!E->have_U) { chs_set_error("chs_get_mu: no field uploaded"); return CHS_ESTATE; }
+  E->resident = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   DevState s;
   CHS_HIP(hipStreamSynchronize(E->stream));

@@ -145,6 +145,9 @@ struct Engine {
   bool prepared = false;
   bool have_U = false;
   bool hat_valid = false;  // dHat matches dU's history (CHS_STEP_CARRY_HAT)
+  bool resident = false;   // ... and T1 / partMu hold the row transform of EnergieEut(U) and its sum of squares: the
+                           // next call continues without an entry pass (the last fused step left them, chs_fast_step)
+  bool keepResident = false;  // this call's last step runs the fused row kernel so that the next call can continue
 
   // device buffers (element type per dtype)
   void* dU = nullptr;      // field U, row-major N x N

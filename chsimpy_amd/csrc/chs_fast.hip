@@ -241,7 +241,16 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   if (rc) return rc;
   chs_slot_begin(E, SLOT_INV);
   const bool fa = fused_adaptive(E);
-  rc = P->row_inv(E, last ? ROW_INV_DIAG : (fa ? ROW_INV_FUSED_ADAPT : ROW_INV_FUSED), T2, E->dU, E->dT1);
+  if (last && E->keepResident) {
+    // the last step of the call leaves the field in HBM like ROW_INV_DIAG, and with it what the first column
+    // pass of a following call needs (T1, sum(mu^2)): that call then starts without an entry pass (run_steps)
+    const bool store = E->storeU;
+    E->storeU = true;
+    rc = P->row_inv(E, ROW_INV_FUSED, T2, E->dU, E->dT1);
+    E->storeU = store;
+  } else {
+    rc = P->row_inv(E, last ? ROW_INV_DIAG : (fa ? ROW_INV_FUSED_ADAPT : ROW_INV_FUSED), T2, E->dU, E->dT1);
+  }
   chs_slot_end(E, SLOT_INV);
   if (rc) return rc;
   if (!last && E->dc.adaptive_time) {

@@ -35,6 +35,10 @@ class Solver:
         self._pcg = None
         self._pcg_state0 = None  # the default generator's state before the start field was drawn
         self.device_rng = True   # draw start field and jitter noise on the device when the generator is numpy's PCG64
+        # A call that follows a completed call (fixed time step, nothing assigned in between) continues the device
+        # loop where it stopped, hat_U included; True recomputes hat_U = dctn(U) at every call as solver.py:159
+        # does (the same array up to rounding, one transform more per call)
+        self.rederive_hat = False
         self._U_init = None
         # initial concentration field, solver.py:59-82
         if U_init is not None:
@@ -185,7 +189,9 @@ class Solver:
         jitter_on = p.jitter is not None and 0.0 < p.jitter < 0.1
         if not jitter_on:
             eng.set_jitter_noise(0.0, None)
-            rows, rc = eng.step_n(count)
+            # (a call that reaches ntmax ends the run: its last step need not prepare a continuation)
+            rows, rc = eng.step_n(count, rederive_hat=self.rederive_hat,
+                                  last_call=self.solution.computed_steps + count >= p.ntmax)
             self._absorb(rows, rc, count)
         elif self._pcg is not None and self.device_rng:
             # The reference's default generator (numpy PCG64, solver.py:78-82): the device continues

@@ -191,6 +191,51 @@ def test_field_assigned_between_calls_is_picked_up(gpu):
     s.close()
 
 
+@pytest.mark.parametrize("N", [128, 1024])
+@pytest.mark.parametrize("full_sim", [True, False])
+def test_calls_continue_the_device_loop(gpu, N, full_sim):
+    """Fixed time step: a call that follows a completed call continues the device loop where it stopped
+    (hat_U, the row transform of EnergieEut(U) and its sum of squares stay on the device; no dctn(U) on
+    entry, solver.py:159).  A chunked run then gives bit for bit what one call gives, and both stay within
+    tolerance of the oracle's chunks, which recompute hat_U = dctn(U) per call; `rederive_hat` asks the
+    device for that literal recomputation."""
+    chunks = (5, 1, 17, 2, 30)
+    nt = sum(chunks)
+    one = chsimpy_amd.Solver(make(N, nt, 'fast', full_sim=full_sim))
+    one.prepare()
+    sol1 = one.solve_or_resume(nt)
+    U1, td1 = sol1.U.copy(), sol1.timedata.data().copy()
+    one.close()
+    runs = {}
+    for rederive in (False, True):
+        s = chsimpy_amd.Solver(make(N, nt, 'fast', full_sim=full_sim))
+        s.rederive_hat = rederive
+        s.prepare()
+        o = orc.OracleSolver(orc.make_params(N, nt, full_sim=full_sim)) if N <= 128 else None
+        if o:
+            o.prepare()
+        for c in chunks:
+            sol = s.solve_or_resume(c)
+            if o:
+                o.solve_or_resume(c)
+                assert np.allclose(sol.U, o.U, rtol=RTOL, atol=0), (rederive, c, relerr(sol.U, o.U))
+        runs[rederive] = (sol.U.copy(), sol.timedata.data().copy())
+        if o:
+            assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=RTOL, atol=1e-300)
+            # the call that reached ntmax did not prepare a continuation (CHS_STEP_LAST_CALL): one more call
+            # enters through hat_U = dctn(U) again
+            sol = s.solve_or_resume(3); o.solve_or_resume(3)
+            assert np.allclose(sol.U, o.U, rtol=RTOL, atol=0), relerr(sol.U, o.U)
+            assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=RTOL, atol=1e-300)
+        s.close()
+    assert np.array_equal(runs[False][0], U1) and np.array_equal(runs[False][1], td1)
+    # the literal recomputation differs from the carried array by rounding only
+    assert np.allclose(runs[True][0], U1, rtol=1e-11, atol=0), relerr(runs[True][0], U1)
+    assert not np.array_equal(runs[True][0], U1)
+    log_line(f"N={N} full_sim={full_sim} chunks {chunks}: carried hat_U == one call bit for bit; "
+             f"rederive_hat vs carried max rel err U={relerr(runs[True][0], U1):.3e}")
+
+
 def test_simulator_update_every_drives_chunks(gpu, tmp_path):
     """Chunked driving (simulator.py:56-87): `update_every` steps per solve_or_resume, a host snapshot
     handed to the view hook after every chunk, the last chunk shortened to hit ntmax, and the
