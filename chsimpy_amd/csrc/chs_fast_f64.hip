@@ -69,8 +69,13 @@ using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, CHS_PAD1, CH
 
 // fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
 // two rows or two of a tile's four columns per 512-thread workgroup)
-using F8192 = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 4, 4>;
-using F8192C = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 2, 4>;
+// (tiles of 8 columns here: the arrays do not fit the Infinity Cache at this size and the row kernels' 32-byte
+// pieces cost more than k_col's sharing of a line among four workgroups -- row 585 -> 482 us, k_col 680 -> 755 us)
+#ifndef CHS_F8192_CT
+#define CHS_F8192_CT 8
+#endif
+using F8192 = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 4, CHS_F8192_CT>;
+using F8192C = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 2, CHS_F8192_CT>;
 
 
 bool chs_fast_bind_f64(int N, FastPlan* P) {
