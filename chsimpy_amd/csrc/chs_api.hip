@@ -197,6 +197,7 @@ extern "C" int chs_set_U(chs_handle h, const double* host_U) {
   Engine* E = (Engine*)h;
   if (!E || !host_U) { chs_set_error("chs_set_U: null argument"); return CHS_EINVAL; }
   E->resident = false;
+  E->stateCached = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   CHS_HIP(hipStreamSynchronize(E->stream));
   int rc = upload(E, E->dU, host_U);
@@ -217,10 +218,14 @@ extern "C" int chs_get_U(chs_handle h, double* host_U) {
 extern "C" int chs_get_state(chs_handle h, chs_state* out) {
   Engine* E = (Engine*)h;
   if (!E || !out) { chs_set_error("chs_get_state: null argument"); return CHS_EINVAL; }
-  CHS_HIP(hipSetDevice(E->hc.device));
-  CHS_HIP(hipStreamSynchronize(E->stream));
   DevState s;
-  CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+  if (E->stateCached) {
+    s = E->hState[0];  // what the last chs_step_n fetched behind its last kernel; nothing has run since
+  } else {
+    CHS_HIP(hipSetDevice(E->hc.device));
+    CHS_HIP(hipStreamSynchronize(E->stream));
+    CHS_HIP(hipMemcpy(&s, E->dState, sizeof s, hipMemcpyDeviceToHost));
+  }
   out->delt = s.delt; out->time_delta_sum = s.time_delta_sum; out->time_passed = s.time_passed;
   out->tau0 = s.tau0; out->t0 = s.t0; out->computed_steps = s.computed_steps;
   out->skip_check = s.skip_check; out->stop_reason = s.stop_reason;
@@ -231,6 +236,7 @@ extern "C" int chs_set_state(chs_handle h, const chs_state* in) {
   Engine* E = (Engine*)h;
   if (!E || !in) { chs_set_error("chs_set_state: null argument"); return CHS_EINVAL; }
   E->resident = false;
+  E->stateCached = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   CHS_HIP(hipStreamSynchronize(E->stream));
   DevState s;
@@ -249,6 +255,7 @@ extern "C" int chs_prepare(chs_handle h, double row0[9]) {
   if (!E || !row0) { chs_set_error("chs_prepare: null argument"); return CHS_EINVAL; }
   if (!E->have_U) { chs_set_error("chs_prepare: chs_set_U first"); return CHS_ESTATE; }
   E->resident = false;
+  E->stateCached = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   int rc;
   if ((rc = chs_launch_sum(E, 1))) return rc;
@@ -327,6 +334,7 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   if (!E->prepared) { chs_set_error("chs_step_n: not prepared (solver.py:139)"); return CHS_ESTATE; }
   if (nsteps < 0) nsteps = 0;
   CHS_HIP(hipSetDevice(E->hc.device));
+  E->stateCached = false;
   int rc;
   if ((rc = ensure_rows(E))) return rc;
   if (profile) {
@@ -415,6 +423,7 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   }
   if (s.halt) E->hat_valid = false;  // (a deferred tail lets k_col run once past a NaN stop)
   if (nsteps > 0) E->resident = E->keepResident && !s.halt && s.rows_written >= nsteps;
+  E->stateCached = true;  // (the recovery above leaves the device state equal to s)
   int64_t done = s.rows_written;
   if (done > nsteps) done = nsteps;
   if (steps_done) *steps_done = done;
@@ -471,6 +480,7 @@ extern "C" int chs_init_U_pcg64(chs_handle h, double base, double scale, const u
   Engine* E = (Engine*)h;
   if (!E || !state || !inc) { chs_set_error("chs_init_U_pcg64: null argument"); return CHS_EINVAL; }
   E->resident = false;
+  E->stateCached = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   const unsigned long long st[2] = {state[0], state[1]}, ic[2] = {inc[0], inc[1]};
   const int rc = chs_launch_init_pcg(E, base, scale, st, ic);
@@ -512,6 +522,7 @@ extern "C" int chs_dctn(chs_handle h, const double* host_in, double* host_out, i
   Engine* E = (Engine*)h;
   if (!E || !host_in || !host_out) { chs_set_error("chs_dctn: null argument"); return CHS_EINVAL; }
   E->resident = false;
+  E->stateCached = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   CHS_HIP(hipStreamSynchronize(E->stream));
   // dMU/dT2 are scratch between steps
@@ -537,6 +548,7 @@ extern "C" int chs_get_mu(chs_handle h, double* host_mu) {
   if (!E || !host_mu) { chs_set_error("chs_get_mu: null argument"); return CHS_EINVAL; }
   if (!E->have_U) { chs_set_error("chs_get_mu: no field uploaded"); return CHS_ESTATE; }
   E->resident = false;
+  E->stateCached = false;
   CHS_HIP(hipSetDevice(E->hc.device));
   DevState s;
   CHS_HIP(hipStreamSynchronize(E->stream));

@@ -147,6 +147,7 @@ struct Engine {
   bool hat_valid = false;  // dHat matches dU's history (CHS_STEP_CARRY_HAT)
   bool resident = false;   // ... and T1 / partMu hold the row transform of EnergieEut(U) and its sum of squares: the
                            // next call continues without an entry pass (the last fused step left them, chs_fast_step)
+  bool stateCached = false;   // hState[0] is the device state as the last call left it (chs_get_state without a round trip)
   bool keepResident = false;  // this call's last step runs the fused row kernel so that the next call can continue
 
   // device buffers (element type per dtype)
