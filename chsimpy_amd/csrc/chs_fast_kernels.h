@@ -102,6 +102,30 @@ __device__ __forceinline__ int row_of_block(int b) {
   }
 }
 
+// Lanes of a row workgroup.  Two rows per workgroup, transforms of whole wavefronts (N >= 4096): every wavefront
+// takes 32 lanes of EACH row (lane i the first row, lane i+32 the second, same butterfly index), so that a
+// wave-load of the tile-major operand touches the two rows' neighbouring pieces -- 64 contiguous bytes per tile
+// instead of 32 (tools/ubench/strided_rows.hip: the access pattern alone 84 -> 40 us at N=4096 fp64).  Measured on
+// the kernels: N=8192 fp64 row 481 -> 435 us (+3 % steps/s), fp32 332 -> 322 us; N=4096 fp64 row -2 % but k_col
+// behind it +4 % (net -0.8 %), so it is on from CHS_ROW_INTERLEAVE_MIN_N upwards only.
+#ifndef CHS_ROW_INTERLEAVE
+#define CHS_ROW_INTERLEAVE 1
+#endif
+#ifndef CHS_ROW_INTERLEAVE_MIN_N
+#define CHS_ROW_INTERLEAVE_MIN_N 8192
+#endif
+template <class C>
+__device__ __forceinline__ void row_lane_map(int& l, int& sub) {
+  if constexpr ((CHS_ROW_INTERLEAVE != 0) && C::C == 2 && (C::G % 64 == 0) && C::N >= CHS_ROW_INTERLEAVE_MIN_N) {
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    sub = ln >> 5;
+    l = w * 32 + (ln & 31);
+  } else {
+    l = threadIdx.x % C::G;
+    sub = threadIdx.x / C::G;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, T q[4]) {
   if constexpr (sizeof(T) == 8) {
@@ -243,7 +267,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
   __shared__ double red[32];
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
-  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
+  int l, sub;
+  row_lane_map<C>(l, sub);
   const int row = row_of_block<C>(blockIdx.x) + sub;
   T* scr = lds + (size_t)sub * C::SCR;
   T re[C::E], im[C::E];
@@ -319,7 +344,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
   __shared__ double red[32];
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
-  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
+  int l, sub;
+  row_lane_map<C>(l, sub);
   const int row = row_of_block<C>(blockIdx.x) + sub;
   T* scr = lds + (size_t)sub * C::SCR;
   double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
@@ -406,7 +432,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   __shared__ double red[64];
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
-  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
+  int l, sub;
+  row_lane_map<C>(l, sub);
   if constexpr (DIAG && FUSE) stagger_start<CHS_STAGGER_ROW>();
   const double mean_u = st->meanU;  // requested at entry (k_col of this step wrote it), used in the pointwise part
   // reduction table of the table-driven log, behind the exchange scratch (visible after the first barrier)
