@@ -11,7 +11,8 @@ from chsimpy_amd import _lib
 
 NST = 12
 p = chsimpy_amd.Parameters()
-p.N, p.ntmax, p.full_sim, p.kappa_tilde = 4096, 10 ** 9, True, 0.0002989112919661156
+NN = int(os.environ.get('CHS_STAMP_N', '4096'))
+p.N, p.ntmax, p.full_sim, p.kappa_tilde = NN, 10 ** 9, True, 0.0002989112919661156
 s = chsimpy_amd.Solver(p)
 s.prepare()
 s.solve_or_resume(6)
@@ -19,7 +20,8 @@ lib = _lib.load()
 lib.chs_debug_stamps.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
 names = {0: ['recombine^T (T2 loads)', 'inv passes', 'store U', 'pointwise (+edges)', 'fwd passes', 'recombine (T1 stores)'],
          1: ['stage in (tile loads)', 'fwd passes', 'spectral (hat r/w)', 'inv passes', 'stage out']}
-for which, nblk in ((0, 2048), (1, 2048)):
+NB = int(os.environ.get('CHS_STAMP_BLOCKS', '2048'))
+for which, nblk in ((0, NB), (1, NB)):
     buf = np.zeros(8192 * NST, dtype=np.uint64)
     rc = lib.chs_debug_stamps(which, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size)
     st = buf.reshape(8192, NST)[:nblk].astype(np.int64)
@@ -31,12 +33,12 @@ for which, nblk in ((0, 2048), (1, 2048)):
     if which == 0:
         r1 = st[:, 7:11]   # wave 1 of k_col (plain recombination path) parks its stamps in kernel 0's free slots
         k1 = r1[:, 0] > 0
-        print('   k_col wave 1 (plain path): slot 0', int(np.median(r1[k1, 1] - r1[k1, 0])), '| slots 1-3',
+        if k1.any(): print('   k_col wave 1 (plain path): slot 0', int(np.median(r1[k1, 1] - r1[k1, 0])), '| slots 1-3',
               int(np.median(r1[k1, 2] - r1[k1, 1])), '| slots 4-7', int(np.median(r1[k1, 3] - r1[k1, 2])))
     if which == 1:
         r = st[:, 6:10]
         okk = (r[:, 0] > 0) & (st[:, 2] > 0)
-        print('   wave 0 inside the recombination: fwd done -> enter', int(np.median(r[okk, 0] - st[okk, 2])),
+        if okk.any(): print('   wave 0 inside the recombination: fwd done -> enter', int(np.median(r[okk, 0] - st[okk, 2])),
               '| special slot', int(np.median(r[okk, 1] - r[okk, 0])), '| slot 0', int(np.median(r[okk, 2] - r[okk, 1])),
               '| slots 1-3', int(np.median(r[okk, 3] - r[okk, 2])), '| slots 4-7', int(np.median(st[okk, 10] - r[okk, 3])),
               '| end of the slots -> past the join (wait for the hat_U stores)', int(np.median(st[okk, 3] - st[okk, 10])))
