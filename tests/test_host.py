@@ -30,6 +30,18 @@ def test_library_loads_and_exports_every_declared_symbol(hip_lib):
     assert b'gfx950' in hip_lib.chs_version()
 
 
+def test_header_constants_match_the_binding():
+    """Every `#define CHS_<NAME> <integer>` of include/chs_hip.h that the ctypes binding mirrors has the same value there."""
+    hdr = open(os.path.join(ROOT, 'include', 'chs_hip.h')).read()
+    defs = {k: int(v, 0) for k, v in re.findall(r'#define\s+(CHS_[A-Z_0-9]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b', hdr)}
+    for name in ('CHS_STEP_CARRY_HAT', 'CHS_STEP_REDERIVE_HAT', 'CHS_STEP_LAST_CALL'):
+        assert name in defs, name
+    mirrored = [k for k in defs if hasattr(_lib, k)]
+    assert len(mirrored) >= 6
+    for k in mirrored:
+        assert getattr(_lib, k) == defs[k], k
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.chs_consts) == 6 * 4 + 14 * 8
     assert ctypes.sizeof(_lib.chs_state) == 5 * 8 + 8 + 2 * 4
