@@ -236,6 +236,50 @@ def test_calls_continue_the_device_loop(gpu, N, full_sim):
              f"rederive_hat vs carried max rel err U={relerr(runs[True][0], U1):.3e}")
 
 
+@pytest.mark.parametrize("full_sim,seed", [(True, 1), (False, 2), (True, 3), (False, 4), (True, 5), (False, 6)])
+def test_interleaved_engine_calls_keep_the_loop_state_right(gpu, full_sim, seed):
+    """The device keeps hat_U, the row transform of EnergieEut(U) and its sum of squares between calls and the
+    last call's state for chs_get_state; everything that can invalidate them is thrown in between the chunks in a
+    seeded random order: field downloads, a field assigned by the caller, the scratch-using entry points
+    (chs_dctn, chs_get_mu), profiled steps' absence aside.  Every chunk is compared with the oracle doing the same."""
+    N = 128
+    rng = np.random.default_rng(seed)
+    s = chsimpy_amd.Solver(make(N, 10 ** 6, 'fast', full_sim=full_sim))
+    o = orc.OracleSolver(orc.make_params(N, 10 ** 6, full_sim=full_sim))
+    s.prepare(); o.prepare()
+    eng = s._engine
+    done = 0
+    ops = []
+    while done < 140:
+        op = rng.choice(['step', 'step', 'step', 'step', 'getU', 'setU', 'dctn', 'mu', 'state', 'toggle'])
+        ops.append(op)
+        if op == 'step':
+            n = int(rng.integers(1, 9))
+            sol = s.solve_or_resume(n); o.solve_or_resume(n)
+            done += n
+            assert sol.computed_steps == o.computed_steps, ops
+            assert np.allclose(sol.timedata.data(), o.timedata.data(), rtol=RTOL, atol=1e-300), ops
+        elif op == 'getU':
+            assert np.allclose(s.solution.U, o.U, rtol=RTOL, atol=0), ops
+        elif op == 'setU':
+            V = np.clip(o.U * (1.0 + 1e-4 * rng.standard_normal((N, N))), 0.7, 0.97)
+            s.solution.U = V
+            o.U = V.copy()
+        elif op == 'dctn':
+            X = rng.random((N, N))
+            from scipy.fft import dctn
+            assert np.allclose(eng.dctn(X), dctn(X, norm='ortho'), rtol=1e-11, atol=1e-12), ops
+        elif op == 'mu':
+            eng.get_mu()
+        elif op == 'toggle':
+            s.rederive_hat = not s.rederive_hat
+        else:
+            st = eng.get_state()
+            assert st.computed_steps == o.computed_steps and st.time_passed == pytest.approx(o.time_passed, rel=1e-12), ops
+    assert np.allclose(s.solution.U, o.U, rtol=RTOL, atol=0), (ops, relerr(s.solution.U, o.U))
+    s.close()
+
+
 def test_simulator_update_every_drives_chunks(gpu, tmp_path):
     """Chunked driving (simulator.py:56-87): `update_every` steps per solve_or_resume, a host snapshot
     handed to the view hook after every chunk, the last chunk shortened to hit ntmax, and the
