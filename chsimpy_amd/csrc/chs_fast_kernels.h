@@ -701,7 +701,16 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   using T = typename C::T;
   using CS = ColStage<C>;
   __shared__ double red[32];
-  if (st->halt) return;
+  if constexpr (MODE == MODE_STEP) {
+    // block 0 of this very launch may raise the stop flag (the riding tail): one thread reads it for the whole
+    // workgroup, so that all its wavefronts leave or stay together
+    __shared__ int halted;
+    if (threadIdx.x == 0) halted = st->halt;
+    __syncthreads();
+    if (halted) return;
+  } else {
+    if (st->halt) return;
+  }
   if constexpr (MODE == MODE_STEP) stagger_start<CHS_STAGGER_COL>();
   if constexpr (MODE == MODE_STEP) STAMP(1, 0);
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
