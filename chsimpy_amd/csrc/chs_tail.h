@@ -109,6 +109,14 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
   const bool adapt = do_pre && dc.adaptive_time && cs_next > 500 && (cs_next % 2) == 0;
   double v[NV] = {0, 0, 0, 0, 0, 0, 0, 0};  // sE, sEdge, sPS, cSA, spectral, musq, -, -
   double mn = 1.0e300;
+  // the state and Ra are thread 0's operands at the very end: asked for here, with everything else, they cost
+  // no round trip of their own behind the reductions (nobody else writes the fields used below in the meantime)
+  DevState loc;
+  double Ra = 0.0;
+  if (tid == 0) {
+    loc = *st;
+    if (!ta.pre_only) Ra = ta.partRa[0];
+  }
   if (ta.pre_only) {
     // sum(mu^2) of the entry kernel -> L2 and the time bookkeeping of the first step (k_pre's work; fixed
     // time step: nothing k_col of this step reads changes)
@@ -119,7 +127,6 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
     if (tid == 0) {
       double t = red[0];
       for (int w = 1; w < NW; ++w) t += red[w];
-      DevState loc = *st;
       pre_update(dc, &loc, t, false, 0.0);
       st->delt = loc.delt; st->delt_coef = loc.delt_coef; st->time_delta_sum = loc.time_delta_sum;
       st->time_passed = loc.time_passed; st->L2_cur = loc.L2_cur; st->lam1 = loc.lam1; st->lam2 = loc.lam2;
@@ -172,16 +179,14 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
   __syncthreads();
   if (tid == 0) {
 #pragma clang fp contract(off)
-    const double Ra = ta.partRa[0];
     const double N2 = (double)N * (double)N;
     const double L2sq = dc.L * dc.L;
     // np.gradient's sum of squares from the spectrum + the one-sided edge rows/columns (see k_fin)
     const double sG = (4.0 * tot[4] + 3.0 * tot[1]) / (4.0 * dc.delx * dc.delx);
     const double E2 = 0.5 * dc.Amr * dc.kappa_tilde * L2sq * (sG / N2);
     const double E = dc.Amr * L2sq * (tot[0] / N2) + E2;
-    // work on a register copy of the state: one wide load and one wide store instead of a
+    // work on a register copy of the state (loaded at the top): one wide load and one wide store instead of a
     // chain of dependent global round trips
-    DevState loc = *st;
     fin_update(dc, &loc, E, E2, tot[2] / N2, tot[3] / N2, Ra, ta.rows, ta.rowsCap);
     if (do_pre && !loc.halt) pre_update(dc, &loc, tot[5], adapt, tot[NV]);
     // write back everything except meanU: when the tail rides in k_col of the NEXT step, that
