@@ -94,6 +94,9 @@ struct TailArgs {
 };
 
 #define TAIL_NV 8
+#ifndef TAIL_UN
+#define TAIL_UN 8  // independent requests per thread and batch
+#endif
 #define TAIL_RED_DOUBLES(THREADS) (((THREADS) / 64 + 1) * (TAIL_NV + 1))
 
 // One workgroup of THREADS threads; `red` = TAIL_RED_DOUBLES(THREADS) doubles of LDS.  Every input
@@ -120,7 +123,13 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
   if (ta.pre_only) {
     // sum(mu^2) of the entry kernel -> L2 and the time bookkeeping of the first step (k_pre's work; fixed
     // time step: nothing k_col of this step reads changes)
-    for (int i = tid; i < ta.nMu; i += THREADS) v[5] += ta.partMu[i];
+    for (int i0 = tid; i0 < ta.nMu; i0 += THREADS * TAIL_UN) {
+      double x[TAIL_UN];
+#pragma unroll
+      for (int u = 0; u < TAIL_UN; ++u) { const int i = i0 + u * THREADS; x[u] = ta.partMu[i < ta.nMu ? i : 0]; }
+#pragma unroll
+      for (int u = 0; u < TAIL_UN; ++u) v[5] += (i0 + u * THREADS < ta.nMu) ? x[u] : 0.0;
+    }
     v[5] = wave_sum(v[5]);
     if (lane == 0) red[wave] = v[5];
     __syncthreads();
@@ -134,34 +143,67 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
     }
     return;
   }
-  for (int i = tid; i < ta.nRow; i += THREADS) {
-    v[0] += ta.partDiag[(size_t)i * 4 + 0];
-    v[1] += ta.partDiag[(size_t)i * 4 + 1];
-    v[2] += ta.partDiag[(size_t)i * 4 + 2];
-    v[3] += ta.partDiag[(size_t)i * 4 + 3];
+  // Batches of TAIL_UN independent requests per thread (a rolled loop would wait for every element before it
+  // asks for the next: ~40 dependent round trips, 14 us as a kernel of its own and twice that while the tiles
+  // of the carrying k_col stream in); out-of-range slots read element 0 and add zero, the order of the sums
+  // is that of the plain loops.
+  constexpr int UN = TAIL_UN;
+  for (int i0 = tid; i0 < ta.nRow; i0 += THREADS * UN) {
+    double2 a[UN], b[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * THREADS;
+      const double2* q = reinterpret_cast<const double2*>(ta.partDiag + (size_t)(i < ta.nRow ? i : 0) * 4);
+      a[u] = q[0]; b[u] = q[1];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bool ok = i0 + u * THREADS < ta.nRow;
+      v[0] += ok ? a[u].x : 0.0; v[1] += ok ? a[u].y : 0.0; v[2] += ok ? b[u].x : 0.0; v[3] += ok ? b[u].y : 0.0;
+    }
   }
-  for (int i = tid; i < ta.nE2; i += THREADS) v[4] += ta.partE2[i];
+  auto sum_batched = [&](const double* __restrict__ src, int n, double& acc) {
+    for (int i0 = tid; i0 < n; i0 += THREADS * UN) {
+      double x[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { const int i = i0 + u * THREADS; x[u] = src[i < n ? i : 0]; }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) acc += (i0 + u * THREADS < n) ? x[u] : 0.0;
+    }
+  };
+  sum_batched(ta.partE2, ta.nE2, v[4]);
   // one-sided row edges of np.gradient (solver.py:213-217): (U[1,c]-U[0,c])^2 + (U[N-1,c]-U[N-2,c])^2;
   // the row kernel adds the column edges, k_col the spectral bulk
   if (ta.U) {
-    const size_t last = (size_t)(N - 2) * N;
-    for (int c = tid; c < N; c += THREADS) {
-      double a0, a1, b0, b1;
-      if (ta.f32) {
-        const float* u = (const float*)ta.U;
-        a0 = u[c]; a1 = u[N + c]; b0 = u[last + c]; b1 = u[last + N + c];
-      } else {
-        const double* u = (const double*)ta.U;
-        a0 = u[c]; a1 = u[N + c]; b0 = u[last + c]; b1 = u[last + N + c];
+    auto edges = [&](auto* uu) {  // (one instantiation per element type: no type branch inside the batches)
+      const size_t last = (size_t)(N - 2) * N;
+      for (int c0 = tid; c0 < N; c0 += THREADS * UN) {
+        double a0[UN], a1[UN], b0[UN], b1[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int c = (c0 + u * THREADS < N) ? c0 + u * THREADS : 0;
+          a0[u] = (double)uu[c]; a1[u] = (double)uu[N + c]; b0[u] = (double)uu[last + c]; b1[u] = (double)uu[last + N + c];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const double d0 = a1[u] - a0[u], d1 = b1[u] - b0[u];
+          v[1] += (c0 + u * THREADS < N) ? d0 * d0 + d1 * d1 : 0.0;
+        }
       }
-      const double d0 = a1 - a0, d1 = b1 - b0;
-      v[1] += d0 * d0 + d1 * d1;
+    };
+    if (ta.f32) edges((const float*)ta.U);
+    else edges((const double*)ta.U);
+  }
+  if (do_pre) sum_batched(ta.partMu, ta.nMu, v[5]);
+  if (adapt) {
+    for (int i0 = tid; i0 < ta.nColMin; i0 += THREADS * UN) {
+      double x[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { const int i = i0 + u * THREADS; x[u] = ta.partColMin[i < ta.nColMin ? i : 0]; }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) mn = (i0 + u * THREADS < ta.nColMin) ? fmin(mn, x[u]) : mn;
     }
   }
-  if (do_pre)
-    for (int i = tid; i < ta.nMu; i += THREADS) v[5] += ta.partMu[i];
-  if (adapt)
-    for (int i = tid; i < ta.nColMin; i += THREADS) mn = fmin(mn, ta.partColMin[i]);
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
   mn = wave_min(mn);
