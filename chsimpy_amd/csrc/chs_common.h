@@ -195,6 +195,7 @@ struct Engine {
   unsigned long long pcgState[2] = {0, 0}, pcgInc[2] = {0, 0};  // {hi, lo}
   bool fusedAdapt = false;    // the fused row kernel adds up the adaptive-step integrand itself
   double* dPartColRows = nullptr;  // [nRowBlocks][N] partial column sums of that integrand
+  double* dColSlices = nullptr;    // [CS_SLICES][N] first stage of their reduction (chs_launch_colmin_rows)
   bool storeU = true;         // the fused row kernel writes U on intermediate steps (chs_fast_step)
   int tailSet = 0;            // ... on this partial set
   hipEvent_t evA = nullptr, evB = nullptr;
@@ -225,7 +226,7 @@ void chs_slot_end(Engine* E, int slot);
 // slots
 enum {
   SLOT_MU = 0,      // direct: pointwise EnergieEut           | fast: row pass forward (mu + DCT-II rows)
-  SLOT_PRE = 1,     // k_pre (+ k_colmin): L2, adaptive dt, time bookkeeping
+  SLOT_PRE = 1,     // k_pre (+ the column-sum minimum): L2, adaptive dt, time bookkeeping
   SLOT_FWD = 2,     // direct: the two forward products       | fast: (unused)
   SLOT_SPEC = 3,    // direct: spectral update                | fast: column pass (DCT-II, update, DCT-III)
   SLOT_INV = 4,     // direct: the two inverse products       | fast: row pass inverse (DCT-III rows)

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     // Adaptive step (solver.py:177-183): on the steps whose successor re-evaluates delt, the column
     // sums of delt_max/sqrt(1 + alpha*mu^2) are needed.  mu of the next step is in the registers
     // right now: every workgroup adds up its rows per column (through the idle exchange scratch) and
-    // writes one partial row; k_colmin sums the partial rows and takes the minimum.  No sweep of U.
+    // writes one partial row; k_colsum_slices / k_colmin_slices add them up and take the minimum.  No sweep of U.
     // NH passes over the columns when a row of doubles does not fit the scratch (fp32 transforms)
     constexpr int LDSB = C::C * C::SCR * (int)sizeof(T);
     constexpr int NH = (C::C == 1 || C::N * 8 <= LDSB) ? 1 : 2;

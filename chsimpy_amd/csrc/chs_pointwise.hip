@@ -3,7 +3,7 @@
 //
 // Reference lines implemented here:
 //   k_mu        chsimpy/solver.py:166-175 (+ the operands of 183 and 225)
-//   k_colmin    chsimpy/solver.py:183  (np.linalg.norm(.., ord=-1) = min column abs-sum)
+//   k_colsum_slices / k_colmin_slices    chsimpy/solver.py:183  (np.linalg.norm(.., ord=-1) = min column abs-sum)
 //   k_pre       chsimpy/solver.py:177-199,225
 //   k_spectral  chsimpy/solver.py:201-206 with chsimpy/utils.py:39-49
 //   k_diag      chsimpy/solver.py:213-228 (= 100-116 for prepare)
@@ -52,27 +52,6 @@ __global__ __launch_bounds__(PW_THREADS) void k_mu(const T* __restrict__ U, T* _
   }
   const double tot = block_sum(s2, scratch);
   if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
-}
-
-// ---------------------------------------------------------------------------
-// k_colmin: column sums over the row bands, then the minimum over the block's
-// columns.  grid.x = ceil(N/PW_THREADS).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(PW_THREADS) void k_colmin(const double* __restrict__ partCol, int nBands, int N,
-                                                       const DevState* __restrict__ st, int adaptive,
-                                                       double* __restrict__ partColMin, int cs_offset) {
-  __shared__ double scratch[32];
-  if (st->halt) return;
-  const long long cs = st->computed_steps + cs_offset;
-  if (!(adaptive && cs > 500 && (cs % 2) == 0)) return;
-  const int c = blockIdx.x * PW_THREADS + threadIdx.x;
-  double s = 1.0e300;
-  if (c < N) {
-    s = 0.0;
-    for (int b = 0; b < nBands; ++b) s += partCol[(size_t)b * N + c];
-  }
-  const double m = block_min(s, scratch);
-  if (threadIdx.x == 0) partColMin[blockIdx.x] = m;
 }
 
 // ---------------------------------------------------------------------------
@@ -491,13 +470,14 @@ int chs_pointwise_alloc(Engine* E) {
   CHS_HIP(hipMalloc(&E->dPartMuAux, sizeof(double) * (size_t)E->nBands));
   CHS_HIP(hipMalloc(&E->dPartDiag, sizeof(double) * 4 * (size_t)(E->nDiagBlocks > N ? E->nDiagBlocks : N)));
   CHS_HIP(hipMalloc(&E->dPartSum, sizeof(double) * (size_t)(E->nBands > CHS_JITTER_BLOCKS_MAX ? E->nBands : CHS_JITTER_BLOCKS_MAX)));
-  CHS_HIP(hipMalloc(&E->dPartColMin, sizeof(double) * (size_t)((N + 31) / 32)));  // k_colmin: N/256 entries, k_colmin_rows: N/32
+  CHS_HIP(hipMalloc(&E->dPartColMin, sizeof(double) * (size_t)((N + 31) / 32)));  // (k_colmin_slices writes N/256 entries)
   CHS_HIP(hipMalloc(&E->dPartCol, sizeof(double) * (size_t)E->nBands * N));
   return CHS_OK;
 }
 void chs_pointwise_free(Engine* E) {
   hipFree(E->dPartMu); hipFree(E->dPartMuAux); hipFree(E->dPartDiag); hipFree(E->dPartSum);
   hipFree(E->dPartColMin); hipFree(E->dPartCol);
+  if (E->dColSlices) { hipFree(E->dColSlices); E->dColSlices = nullptr; }
 }
 
 
@@ -513,6 +493,8 @@ int chs_launch_mu(Engine* E) {
   return CHS_OK;
 }
 
+static int launch_colmin(Engine* E, const double* rows, int nRows, int cs_offset);
+
 int chs_launch_mu_colsums(Engine* E, int cs_offset) {
   chs_slot_begin(E, SLOT_MISC);
   DISPATCH_T(E,
@@ -520,59 +502,101 @@ int chs_launch_mu_colsums(Engine* E, int cs_offset) {
                                                             E->dPartMuAux, E->dPartCol, 1, cs_offset)),
     (k_mu<float><<<E->nBands, PW_THREADS, 0, E->stream>>>((const float*)E->dU, (float*)E->dMU, E->dc, E->dState,
                                                            E->dPartMuAux, E->dPartCol, 1, cs_offset)));
-  k_colmin<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dPartCol, E->nBands, E->N, E->dState,
-                                                            E->dc.adaptive_time, E->dPartColMin, cs_offset);
-  E->nColMinCur = E->nColMinBlocks;
+  const int rcm = launch_colmin(E, E->dPartCol, E->nBands, cs_offset);
   chs_slot_end(E, SLOT_MISC);
+  if (rcm) return rcm;
   CHS_HIP(hipGetLastError());
   return CHS_OK;
 }
 
-// k_colmin_rows: the same for the partial rows the fused row kernel writes (one per workgroup: up to
-// N/2 of them).  A block owns 32 columns; 8 thread groups stride the rows, LDS adds them up.
-// Writes to partColMin[nColMinBlocks + blockIdx.x] (the second part of the buffer).
-#define CMR_COLS 32
-__global__ __launch_bounds__(PW_THREADS) void k_colmin_rows(const double* __restrict__ partRows, int nRows, int N,
-                                                            const DevState* __restrict__ st, int adaptive,
-                                                            double* __restrict__ partColMin, int cs_offset) {
+// k_colsum_slices / k_colmin_slices: the same for the partial rows the fused row kernel writes (one per workgroup:
+// up to N/2 of them, 67 MB at N=4096).  Two stages so that the array streams: CS_SLICES x N/64 blocks add up
+// 64 columns over one slice of the rows each (a wavefront reads 512 contiguous bytes per row, 8 independent
+// requests per thread in flight), then one thread per column adds the slices and the block takes the minimum.
+// (One block per 32 columns with a rolled loop over all rows -- 128 blocks, one request in flight per thread --
+// took longer than the step's two transform kernels together.)
+#define CS_COLS 64
+#define CS_SLICES 32
+#define CS_UN 8
+__global__ __launch_bounds__(PW_THREADS) void k_colsum_slices(const double* __restrict__ partRows, int nRows, int N,
+                                                              const DevState* __restrict__ st, int adaptive,
+                                                              double* __restrict__ slices, int cs_offset) {
   __shared__ double acc[PW_THREADS];
   if (st->halt) return;
   const long long cs = st->computed_steps + cs_offset;
   if (!(adaptive && cs > 500 && (cs % 2) == 0)) return;
-  constexpr int RG = PW_THREADS / CMR_COLS;
-  const int cx = threadIdx.x % CMR_COLS, ry = threadIdx.x / CMR_COLS;
-  const int c = blockIdx.x * CMR_COLS + cx;
+  constexpr int NWV = PW_THREADS / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * CS_COLS + lane;
+  const int per = (nRows + CS_SLICES - 1) / CS_SLICES;
+  const int r0 = blockIdx.y * per, r1 = min(r0 + per, nRows);
   double s = 0.0;
-  if (c < N)
-    for (int r = ry; r < nRows; r += RG) s += partRows[(size_t)r * N + c];
+  if (c < N) {
+    const double* col = partRows + c;
+    for (int rb = r0 + w; rb < r1; rb += NWV * CS_UN) {
+      double x[CS_UN];
+#pragma unroll
+      for (int u = 0; u < CS_UN; ++u) { const int r = rb + u * NWV; x[u] = col[(size_t)(r < r1 ? r : r0) * N]; }
+#pragma unroll
+      for (int u = 0; u < CS_UN; ++u) s += (rb + u * NWV < r1) ? x[u] : 0.0;
+    }
+  }
   acc[threadIdx.x] = s;
   __syncthreads();
-  if (ry == 0) {
-    double t = acc[cx];
-    for (int g = 1; g < RG; ++g) t += acc[g * CMR_COLS + cx];
-    if (c >= N) t = 1.0e300;
-    // minimum over the block's 32 columns (they sit in the first half of wave 0)
-    for (int off = 16; off > 0; off >>= 1) t = fmin(t, __shfl_down(t, off, 64));
-    if (cx == 0) partColMin[blockIdx.x] = t;
+  if (w == 0 && c < N) {
+    double t = acc[lane];
+#pragma unroll
+    for (int g = 1; g < NWV; ++g) t += acc[g * 64 + lane];
+    slices[(size_t)blockIdx.y * N + c] = t;
   }
+}
+__global__ __launch_bounds__(PW_THREADS) void k_colmin_slices(const double* __restrict__ slices, int N,
+                                                              const DevState* __restrict__ st, int adaptive,
+                                                              double* __restrict__ partColMin, int cs_offset) {
+  __shared__ double scratch[32];
+  if (st->halt) return;
+  const long long cs = st->computed_steps + cs_offset;
+  if (!(adaptive && cs > 500 && (cs % 2) == 0)) return;
+  const int c = blockIdx.x * PW_THREADS + threadIdx.x;
+  double s = 1.0e300;
+  if (c < N) {
+    double x[CS_SLICES];
+#pragma unroll
+    for (int b = 0; b < CS_SLICES; ++b) x[b] = slices[(size_t)b * N + c];
+    s = 0.0;
+#pragma unroll
+    for (int b = 0; b < CS_SLICES; ++b) s += x[b];
+  }
+  const double m = block_min(s, scratch);
+  if (threadIdx.x == 0) partColMin[blockIdx.x] = m;
+}
+
+// partColMin[0 .. nColMinBlocks) <- block minima of the column sums of rows[nRows][N]
+static int launch_colmin(Engine* E, const double* rows, int nRows, int cs_offset) {
+  if (!E->dColSlices) CHS_HIP(hipMalloc(&E->dColSlices, sizeof(double) * (size_t)CS_SLICES * E->N));
+  const dim3 g1((E->N + CS_COLS - 1) / CS_COLS, CS_SLICES);
+  k_colsum_slices<<<g1, PW_THREADS, 0, E->stream>>>(rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
+  k_colmin_slices<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dColSlices, E->N, E->dState, E->dc.adaptive_time,
+                                                                  E->dPartColMin, cs_offset);
+  E->nColMinCur = E->nColMinBlocks;
+  return CHS_OK;
 }
 
 int chs_launch_colmin_rows(Engine* E, int cs_offset) {
   chs_slot_begin(E, SLOT_MISC);
-  const int nb = (E->N + CMR_COLS - 1) / CMR_COLS;
-  k_colmin_rows<<<nb, PW_THREADS, 0, E->stream>>>(E->dPartColRows, E->nRowBlocks, E->N, E->dState,
-                                                   E->dc.adaptive_time, E->dPartColMin, cs_offset);
-  E->nColMinCur = nb;
+  const int rc = launch_colmin(E, E->dPartColRows, E->nRowBlocks, cs_offset);
   chs_slot_end(E, SLOT_MISC);
+  if (rc) return rc;
   CHS_HIP(hipGetLastError());
   return CHS_OK;
 }
 
 int chs_launch_pre(Engine* E) {
   chs_slot_begin(E, SLOT_PRE);
-  if (E->dc.adaptive_time && E->engine == CHS_ENGINE_DIRECT)
-    k_colmin<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dPartCol, E->nBands, E->N, E->dState,
-                                                              E->dc.adaptive_time, E->dPartColMin, 0);
+  if (E->dc.adaptive_time && E->engine == CHS_ENGINE_DIRECT) {
+    const int rcm = launch_colmin(E, E->dPartCol, E->nBands, 0);
+    if (rcm) { chs_slot_end(E, SLOT_PRE); return rcm; }
+  }
   k_pre<<<1, PW_THREADS, 0, E->stream>>>(E->dc, E->dState, E->dPartMu, E->nPartMu, E->dPartColMin,
                                          E->nColMinBlocks);
   chs_slot_end(E, SLOT_PRE);
