@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 
 #include "chs_common.h"
@@ -180,15 +182,46 @@ static int upload(Engine* E, void* dst, const double* src) {
   }
   return CHS_OK;
 }
+// Field download through two pinned staging chunks: the DMA of chunk k+1 runs while the host copies (fp32: widens)
+// chunk k into the caller's pageable array -- a direct hipMemcpy into pageable memory took 2-44 ms for 32 MB.
+// The chunks belong to the process (one pair per device, allocated at the first download and kept: pinning
+// 16 MB costs milliseconds, an ensemble creates an engine per member); a mutex serialises the downloads.
+namespace {
+struct StagePair { void* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {}; };
+std::mutex g_stage_mu;
+std::map<int, StagePair> g_stage;  // by device
+}
 static int download(Engine* E, double* dst, const void* src) {
   const size_t n = (size_t)E->N * E->N;
+  const size_t esz = E->esz;
   CHS_HIP(hipStreamSynchronize(E->stream));
-  if (E->dtype == CHS_F64) {
-    CHS_HIP(hipMemcpy(dst, src, n * 8, hipMemcpyDeviceToHost));
-  } else {
-    std::vector<float> tmp(n);
-    CHS_HIP(hipMemcpy(tmp.data(), src, n * 4, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) dst[i] = (double)tmp[i];
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  StagePair& sp = g_stage[E->hc.device];
+  if (!sp.buf[0]) {
+    for (int i = 0; i < 2; ++i) {
+      CHS_HIP(hipHostMalloc(&sp.buf[i], CHS_STAGE_BYTES, hipHostMallocDefault));
+      CHS_HIP(hipEventCreateWithFlags(&sp.ev[i], hipEventDisableTiming));
+    }
+  }
+  const size_t per = CHS_STAGE_BYTES / esz;  // elements per chunk
+  const size_t nch = (n + per - 1) / per;
+  auto issue = [&](size_t k) -> hipError_t {
+    const size_t o = k * per, cnt = (o + per <= n) ? per : n - o;
+    hipError_t e = hipMemcpyAsync(sp.buf[k & 1], (const char*)src + o * esz, cnt * esz, hipMemcpyDeviceToHost, E->stream);
+    if (e != hipSuccess) return e;
+    return hipEventRecord(sp.ev[k & 1], E->stream);
+  };
+  CHS_HIP(issue(0));
+  for (size_t k = 0; k < nch; ++k) {
+    if (k + 1 < nch) CHS_HIP(issue(k + 1));
+    CHS_HIP(hipEventSynchronize(sp.ev[k & 1]));
+    const size_t o = k * per, cnt = (o + per <= n) ? per : n - o;
+    if (E->dtype == CHS_F64) {
+      memcpy(dst + o, sp.buf[k & 1], cnt * 8);
+    } else {
+      const float* f = (const float*)sp.buf[k & 1];
+      for (size_t i = 0; i < cnt; ++i) dst[o + i] = (double)f[i];
+    }
   }
   return CHS_OK;
 }

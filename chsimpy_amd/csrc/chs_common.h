@@ -134,6 +134,7 @@ struct StepTimer {
   hipEvent_t cur = nullptr;      // start event of the open span
 };
 
+#define CHS_STAGE_BYTES (8u << 20)
 struct Engine {
   chs_consts hc;       // as given
   DevConsts dc;        // device view
