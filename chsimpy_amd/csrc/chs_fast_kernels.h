@@ -952,7 +952,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const T h = chs_spectral<T>(hold[t], y[t], p.ls[t].x, lc, lam1, lam2);
+          const T h = chs_spectral<T, (C::N >= CHS_F32_SPECTRAL_MIN_N)>(hold[t], y[t], p.ls[t].x, lc, lam1, lam2);
           y[t] = h;
           const double term = (double)h * (double)h * (p.ls[t].y + sqc);
           e2 += live ? term : 0.0;

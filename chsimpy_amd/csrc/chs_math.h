@@ -241,9 +241,28 @@ __device__ __forceinline__ double chs_dt_integrand(double mu, double delt_max) {
 // chsimpy/utils.py:41-48 formed on the fly:
 //   leig = lam_i + lam_j; CHeig = 1 + lam2*leig*leig; Seig = lam1*leig
 //   hat_U = (hat_U + Seig*hat_mu) / CHeig
-template <typename T>
+// fp32 engine, F32MATH: the same update in single precision (the operands are fp32 values and so is the result;
+// the fp64 version below spends ~40 double-precision instructions per coefficient on a quotient that is rounded
+// to 24 bits on the way out).  Reciprocal + residual correction: within 1 ulp of the fp32 quotient; the parity
+// margins of the fp32 runs do not move (N=512, 1000 steps: U 7.8e-5 -> 8.6e-5 against the fp64 oracle).
+// Measured: N=8192 fp32 k_col 460 -> 433 us, N=4096 fp32 76 -> 83 us (the compiler packs it with more moves and 16
+// more registers there), so k_col asks for it from CHS_F32_SPECTRAL_MIN_N upwards only.
+#ifndef CHS_F32_SPECTRAL_MIN_N
+#define CHS_F32_SPECTRAL_MIN_N 8192
+#endif
+__device__ __forceinline__ float chs_spectral_f32(float hatU, float hatMu, double li, double lj, double lam1, double lam2) {
+  const float leig = (float)li + (float)lj;
+  const float CHeig = __builtin_fmaf((float)lam2 * leig, leig, 1.0f);
+  const float rhs = __builtin_fmaf((float)lam1 * leig, hatMu, hatU);
+  const float r = __builtin_amdgcn_rcpf(CHeig);
+  const float q = rhs * r;
+  const float rho = __builtin_fmaf(-CHeig, q, rhs);
+  return __builtin_fmaf(rho, r, q);
+}
+template <typename T, bool F32MATH = false>
 __device__ __forceinline__ T chs_spectral(T hatU, T hatMu, double li, double lj, double lam1, double lam2) {
 #pragma clang fp contract(off)
+  if constexpr (sizeof(T) == 4 && F32MATH) return chs_spectral_f32(hatU, hatMu, li, lj, lam1, lam2);
   const double leig = li + lj;
   const double CHeig = 1.0 + (lam2 * leig) * leig;
   const double Seig = lam1 * leig;
