@@ -145,24 +145,34 @@ __device__ __forceinline__ double chs_log_unit_tab_f64(double x, const double2* 
   return __builtin_fma((double)e, CHS_LN2, t.y) + lp;
 }
 
+// fp32 engine: x = U, 1-U or their quotient, never denormal: the hardware log2 (1 ulp) times ln 2 instead of the
+// library's range-checked sequence (~10 instructions per logarithm); log of a non-positive number gives NaN / -inf
+// as the library's does.  Every fp32 path uses the same function (the fused kernels and the sweep kernels agree).
+#ifndef CHS_F32_NATIVE_LOG
+#define CHS_F32_NATIVE_LOG 1
+#endif
+__device__ __forceinline__ float chs_logf(float x) {
+  if constexpr (CHS_F32_NATIVE_LOG != 0) return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
+  return logf(x);
+}
 template <typename T> __device__ __forceinline__ T chs_log_pos(T x);
 template <> __device__ __forceinline__ double chs_log_pos<double>(double x) { return chs_log_pos_f64(x); }
-template <> __device__ __forceinline__ float chs_log_pos<float>(float x) { return logf(x); }
+template <> __device__ __forceinline__ float chs_log_pos<float>(float x) { return chs_logf(x); }
 template <typename T> __device__ __forceinline__ T chs_log_unit_tab(T x, const double2* tab, unsigned& domain);
 template <> __device__ __forceinline__ double chs_log_unit_tab<double>(double x, const double2* tab, unsigned& domain) { return chs_log_unit_tab_f64(x, tab, domain); }
 template <> __device__ __forceinline__ float chs_log_unit_tab<float>(float x, const double2*, unsigned& domain) {
   domain = max(domain, (x > 0.0f) ? 0u : ~0u);
-  return logf(x);
+  return chs_logf(x);
 }
 
 template <typename T> __device__ __forceinline__ T chs_log(T x);
 template <> __device__ __forceinline__ double chs_log<double>(double x) { return chs_log_f64(x); }
-template <> __device__ __forceinline__ float chs_log<float>(float x) { return logf(x); }
+template <> __device__ __forceinline__ float chs_log<float>(float x) { return chs_logf(x); }
 
 // log(U / Uinv)
 template <typename T> __device__ __forceinline__ T chs_log_ratio(T a, T b);
 template <> __device__ __forceinline__ double chs_log_ratio<double>(double a, double b) { return chs_log_ratio_f64(a, b); }
-template <> __device__ __forceinline__ float chs_log_ratio<float>(float a, float b) { return logf(a / b); }
+template <> __device__ __forceinline__ float chs_log_ratio<float>(float a, float b) { return chs_logf(a / b); }
 
 // EnergieEut, chsimpy/solver.py:166-175:
 //   Uinv = 1-U; U1Uinv = U/Uinv; U2inv = Uinv-U

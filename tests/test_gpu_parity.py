@@ -446,7 +446,9 @@ def test_fused_adaptive_column_sums_match_the_sweep(gpu, N, dmax, dtype):
     # the fused kernel's shared-log one, so the two agree to fp32 rounding amplified over the steps
     tol = 1e-9 if dtype == 'float64' else 2e-4
     assert np.allclose(tf[:, 8], ts[:, 8], rtol=1e-12 if dtype == 'float64' else 1e-4, atol=0), relerr(tf[:, 8], ts[:, 8])   # delt history
-    assert np.allclose(tf[:, 1:3], ts[:, 1:3], rtol=tol, atol=0)
+    # E2 of these early steps is the start noise growing exponentially (1e-19): in fp32 both paths sit 6.6e-4
+    # (fused) and 8.9e-4 (sweep) from the fp64 run at N=8192 and 2.4e-4 from each other (tools/f32_paths_n8192.py)
+    assert np.allclose(tf[:, 1:3], ts[:, 1:3], rtol=tol if dtype == 'float64' else 1e-3, atol=0)
     assert np.allclose(Uf, Us, rtol=tol, atol=0), relerr(Uf, Us)
 
 
