@@ -111,6 +111,9 @@ __device__ __forceinline__ int row_of_block(int b) {
 #ifndef CHS_ROW_INTERLEAVE
 #define CHS_ROW_INTERLEAVE 1
 #endif
+#ifndef CHS_TAIL_LAST
+#define CHS_TAIL_LAST 1
+#endif
 #ifndef CHS_ROW_INTERLEAVE_MIN_N
 #define CHS_ROW_INTERLEAVE_MIN_N 8192
 #endif
@@ -719,12 +722,16 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     // one extra workgroup, dispatched FIRST (block 0) so that its short chain of dependent loads runs
     // under the first wave of tiles instead of trailing the kernel: the record of the PREVIOUS step
     // and this step's time bookkeeping (chs_fast_step), instead of a launch of its own
+    // Deferred tail (nobody waits for it, ta.gate == 0): the LAST block instead.  The tiles are a whole number of
+    // rounds of workgroups; an extra workgroup at the front pushes its slot's tiles back by its own duration and
+    // the kernel ends that much later, at the back it fills the gap the first slot to finish leaves (CHS_TAIL_LAST).
     if (ta.enabled) {
-      if (bid == 0) {
+      const bool at_end = (CHS_TAIL_LAST != 0) && !ta.gate;
+      if (bid == (at_end ? (int)gridDim.x - 1 : 0)) {
         step_tail_body<C::THREADS>(ta, st, reinterpret_cast<double*>(chs_dyn_lds));
         return;
       }
-      bid -= 1;
+      if (!at_end) bid -= 1;
     }
   }
   // Direct tile access (fp64, two of a tile's four columns per workgroup, groups of whole wavefronts): a
