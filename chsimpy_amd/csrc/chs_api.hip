@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "chs_common.h"
 
@@ -88,6 +89,63 @@ static void free_engine(Engine* E) {
   delete E;
 }
 
+// The device view of the constants of one run.
+static void fill_consts(Engine* E, const chs_consts* c) {
+  const int N = c->N;
+  E->hc = *c;
+  DevConsts& d = E->dc;
+  memset(&d, 0, sizeof d);
+  d.N = N; d.adaptive_time = c->adaptive_time; d.full_sim = c->full_sim;
+  d.RT = c->RT; d.BRT = c->BRT; d.B = c->B; d.A0 = c->A0; d.A1 = c->A1; d.Amr = c->Amr;
+  d.kappa_tilde = c->kappa_tilde; d.L = c->L; d.delx = c->delx;
+  d.delx2 = c->delx * c->delx;  // solution.py:29 `self.delx ** 2`
+  d.delt0 = c->delt; d.delt_max = c->delt_max; d.M_tilde = c->M_tilde; d.threshold = c->threshold;
+  d.time_limit_s = c->time_limit_s;
+  d.invN2 = 1.0 / ((double)N * (double)N);
+}
+static DevState initial_state(const Engine* E) {
+  DevState s0;
+  memset(&s0, 0, sizeof s0);
+  s0.delt = E->hc.delt;
+  s0.delt_coef = E->hc.delt;
+  s0.lam1 = E->hc.delt / E->dc.delx2;
+  s0.lam2 = E->hc.kappa_tilde * s0.lam1 / E->dc.delx2;
+  return s0;
+}
+static void read_env_hooks(Engine* E) {
+  E->batchSteps = 1024;
+  if (const char* bs = getenv("CHS_BATCH_STEPS")) {  // test hook: small batches exercise the polling path
+    const long v = atol(bs);
+    if (v >= 1 && v <= CHS_ROWS_RING / 8) E->batchSteps = (int)v;
+  }
+}
+
+// Engine pool.  An ensemble creates one engine per member, all of one size: chs_destroy parks up to
+// CHS_POOL_MAX engines (fields of at most CHS_POOL_FIELD_BYTES) instead of freeing ~15 device buffers, a stream
+// and the pinned areas, and chs_create takes a parked engine of the same (device, N, dtype, transform engine,
+// eigenvalue table) into use again: new constants, initial state, every per-run flag reset; the buffers are all
+// written before they are read in a run.  CHS_ENGINE_POOL=0 switches it off.
+#define CHS_POOL_MAX 4
+#define CHS_POOL_FIELD_BYTES ((size_t)160 << 20)
+namespace {
+std::mutex g_pool_mu;
+std::vector<Engine*> g_pool;
+bool pool_enabled() { const char* e = getenv("CHS_ENGINE_POOL"); return !(e && e[0] == '0'); }
+}
+static int rearm(Engine* E, const chs_consts* c) {
+  fill_consts(E, c);
+  const DevState s0 = initial_state(E);
+  CHS_HIP(hipMemcpy(E->dState, &s0, sizeof s0, hipMemcpyHostToDevice));
+  E->prepared = false; E->have_U = false; E->hat_valid = false; E->resident = false;
+  E->stateCached = false; E->keepResident = false;
+  E->jitter = 0.0; E->jitterPcg = false;
+  if (E->dNoise) { hipFree(E->dNoise); E->dNoise = nullptr; }
+  E->nColMinCur = 0; E->lastStepMs = 0.0; E->timer.on = false;
+  read_env_hooks(E);
+  if (E->engine == CHS_ENGINE_FAST) return chs_fast_rearm(E);
+  return CHS_OK;
+}
+
 extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle* out) {
   if (!c || !lambda || !out) { chs_set_error("chs_create: null argument"); return CHS_EINVAL; }
   *out = nullptr;
@@ -100,6 +158,29 @@ extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle*
     return CHS_EINVAL;
   }
   CHS_HIP(hipSetDevice(c->device));
+  if (pool_enabled()) {
+    int want = c->engine;
+    if (want == CHS_ENGINE_AUTO) want = chs_fast_supported(c->N, c->dtype) ? CHS_ENGINE_FAST : CHS_ENGINE_DIRECT;
+    Engine* P = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(g_pool_mu);
+      for (size_t i = 0; i < g_pool.size(); ++i) {
+        Engine* Q = g_pool[i];
+        if (Q->hc.device == c->device && Q->N == c->N && Q->dtype == c->dtype && Q->engine == want &&
+            memcmp(Q->hLambda.data(), lambda, sizeof(double) * (size_t)c->N) == 0) {
+          P = Q;
+          g_pool.erase(g_pool.begin() + (long)i);
+          break;
+        }
+      }
+    }
+    if (P) {
+      const int rcp = rearm(P, c);
+      if (rcp) { free_engine(P); return rcp; }
+      *out = (chs_handle)P;
+      return CHS_OK;
+    }
+  }
   Engine* E = new (std::nothrow) Engine();
   if (!E) { chs_set_error("out of host memory"); return CHS_EINVAL; }
   E->hc = *c;
@@ -116,15 +197,8 @@ extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle*
   }
   if (eng != CHS_ENGINE_FAST && eng != CHS_ENGINE_DIRECT) { delete E; chs_set_error("bad engine"); return CHS_EINVAL; }
   E->engine = eng;
+  fill_consts(E, c);
   DevConsts& d = E->dc;
-  memset(&d, 0, sizeof d);
-  d.N = N; d.adaptive_time = c->adaptive_time; d.full_sim = c->full_sim;
-  d.RT = c->RT; d.BRT = c->BRT; d.B = c->B; d.A0 = c->A0; d.A1 = c->A1; d.Amr = c->Amr;
-  d.kappa_tilde = c->kappa_tilde; d.L = c->L; d.delx = c->delx;
-  d.delx2 = c->delx * c->delx;  // solution.py:29 `self.delx ** 2`
-  d.delt0 = c->delt; d.delt_max = c->delt_max; d.M_tilde = c->M_tilde; d.threshold = c->threshold;
-  d.time_limit_s = c->time_limit_s;
-  d.invN2 = 1.0 / ((double)N * (double)N);
 
   int rc = CHS_OK;
   auto fail = [&](int code) { free_engine(E); return code; };
@@ -144,18 +218,11 @@ extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle*
   TRY_HIP(hipMalloc(&E->dLambda, sizeof(double) * N));
   TRY_HIP(hipMemcpy(E->dLambda, lambda, sizeof(double) * N, hipMemcpyHostToDevice));
   TRY_HIP(hipMalloc(&E->dState, sizeof(DevState)));
-  DevState s0;
-  memset(&s0, 0, sizeof s0);
-  s0.delt = c->delt;
-  s0.delt_coef = c->delt;
-  s0.lam1 = c->delt / d.delx2;
-  s0.lam2 = c->kappa_tilde * s0.lam1 / d.delx2;
+  const DevState s0 = initial_state(E);
   TRY_HIP(hipMemcpy(E->dState, &s0, sizeof s0, hipMemcpyHostToDevice));
+  E->hLambda.assign(lambda, lambda + N);
   if ((rc = ensure_rows(E))) return fail(rc);
-  if (const char* bs = getenv("CHS_BATCH_STEPS")) {  // test hook: small batches exercise the polling path
-    const long v = atol(bs);
-    if (v >= 1 && v <= CHS_ROWS_RING / 8) E->batchSteps = (int)v;
-  }
+  read_env_hooks(E);
   if ((rc = chs_pointwise_alloc(E))) return fail(rc);
   if (eng == CHS_ENGINE_DIRECT) rc = chs_direct_init(E); else rc = chs_fast_init(E);
   if (rc) return fail(rc);
@@ -165,7 +232,16 @@ extern "C" int chs_create(const chs_consts* c, const double* lambda, chs_handle*
 }
 
 extern "C" int chs_destroy(chs_handle h) {
-  free_engine((Engine*)h);
+  Engine* E = (Engine*)h;
+  if (!E) return CHS_OK;
+  if (pool_enabled() && (size_t)E->N * E->N * E->esz <= CHS_POOL_FIELD_BYTES) {
+    hipSetDevice(E->hc.device);
+    if (hipStreamSynchronize(E->stream) == hipSuccess) {
+      std::lock_guard<std::mutex> lock(g_pool_mu);
+      if (g_pool.size() < CHS_POOL_MAX) { g_pool.push_back(E); return CHS_OK; }
+    }
+  }
+  free_engine(E);
   return CHS_OK;
 }
 

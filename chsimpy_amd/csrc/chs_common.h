@@ -194,6 +194,7 @@ struct Engine {
   // jitter noise generated on the device: numpy's PCG64 stream continued from the host generator's state
   bool jitterPcg = false;
   unsigned long long pcgState[2] = {0, 0}, pcgInc[2] = {0, 0};  // {hi, lo}
+  bool adaptOk = false;       // the configuration has the fused adaptive row kernel
   bool fusedAdapt = false;    // the fused row kernel adds up the adaptive-step integrand itself
   double* dPartColRows = nullptr;  // [nRowBlocks][N] partial column sums of that integrand
   double* dColSlices = nullptr;    // [CS_SLICES][N] first stage of their reduction (chs_launch_colmin_rows)
@@ -209,6 +210,7 @@ struct Engine {
   double lastStepMs = 0.0;
   StepTimer timer;
   std::vector<double> hostTmp;
+  std::vector<double> hLambda;  // the eigenvalue table the engine was created with (engine pool: chs_create)
 };
 
 void chs_set_error(const std::string& s);
@@ -239,6 +241,7 @@ enum {
 // ---- pointwise / reduction launchers (chs_pointwise.hip) -------------------
 int chs_launch_mu(Engine* E);                 // dU -> dMU, partials
 int chs_launch_mu_colsums(Engine* E, int cs_offset);
+int chs_fast_rearm(Engine* E);
 int chs_launch_colmin_rows(Engine* E, int cs_offset);  // min over the columns of sum(dPartColRows)  // dU -> column-sum minimum of the adaptive-step integrand only
 struct TailArgs;
 TailArgs chs_tail_args(const Engine* E, int set, int do_pre);  // set < 0: the current partial-sum pointers

@@ -100,8 +100,22 @@ int chs_fast_init(Engine* E) {
   CHS_HIP(hipMalloc(&E->partSet[1][1], sizeof(double) * (size_t)(E->nBands > E->N ? E->nBands : E->N)));
   CHS_HIP(hipMalloc(&E->partSet[1][2], sizeof(double) * (size_t)E->nPartE2));
   CHS_HIP(hipMalloc(&E->partSet[1][3], sizeof(double) * 8));
-  if (E->dc.adaptive_time && E->fusedAdapt)
+  return chs_fast_rearm(E);
+}
+
+// What depends on the constants of a run rather than on (N, dtype): called by chs_fast_init and when a pooled engine
+// is taken into use again (chs_create).
+int chs_fast_rearm(Engine* E) {
+  E->fusedAdapt = E->adaptOk && getenv("CHS_ADAPT_SWEEP") == nullptr;
+  if (E->dc.adaptive_time && E->fusedAdapt && !E->dPartColRows)
     CHS_HIP(hipMalloc(&E->dPartColRows, sizeof(double) * (size_t)E->nRowBlocks * E->N));
+  if (E->partSet[0][0]) {
+    E->dPartDiag = E->partSet[0][0]; E->dPartMu = E->partSet[0][1];
+    E->dPartE2 = E->partSet[0][2]; E->dPartRa = E->partSet[0][3];
+  }
+  E->parity = 0; E->tailSet = 0;
+  E->tailDeferred = false; E->tailGated = false; E->preRider = false;
+  E->stepCount = 0; E->storeU = true;
   return CHS_OK;
 }
 

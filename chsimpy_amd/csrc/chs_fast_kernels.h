@@ -1128,6 +1128,7 @@ struct Launch {
     if constexpr (ADAPT_OK) {
       if ((rc = set_lds(k_row_inv<C, true, true, true>, row_lds))) return rc;
     }
+    E->adaptOk = ADAPT_OK;
     E->fusedAdapt = ADAPT_OK && getenv("CHS_ADAPT_SWEEP") == nullptr;  // CHS_ADAPT_SWEEP=1: keep the separate sweep of U
     if ((rc = set_lds(k_col<CC, MODE_STEP>, col_lds))) return rc;
     if ((rc = set_lds(k_col<CC, MODE_FWD_NATIVE>, col_lds))) return rc;
