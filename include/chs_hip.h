@@ -96,7 +96,12 @@ typedef struct chs_handle_s* chs_handle;
  * Environment (read here, test hooks): CHS_ADAPT_SWEEP=1 keeps the separate sweep
  * of U for the adaptive-step column sums instead of the fused row kernel's;
  * CHS_BATCH_STEPS=n issues the steps of a call n at a time (default 1024) -- between
- * batches the host looks at the device's stop flag, see chs_step_n. */
+ * batches the host looks at the device's stop flag, see chs_step_n.
+ * chs_destroy parks up to four engines (fields up to 160 MB) instead of freeing them and chs_create takes a
+ * parked engine of the same device, N, dtype, transform engine and lambda table into use again with the new
+ * constants -- an ensemble creates one engine per member; a run on such an engine is bit for bit the run on
+ * a new one.  CHS_ENGINE_POOL=0 (read at both calls) switches that off.  A handle must not be used after
+ * chs_destroy either way. */
 int chs_create(const chs_consts* consts, const double* lambda, chs_handle* out);
 int chs_destroy(chs_handle h);
 

@@ -280,6 +280,32 @@ def test_interleaved_engine_calls_keep_the_loop_state_right(gpu, full_sim, seed)
     s.close()
 
 
+def test_pooled_engine_equals_fresh_engine(gpu, monkeypatch):
+    """chs_destroy parks engines and chs_create re-arms a parked one of the same size for the next run (an ensemble
+    creates one engine per member): a run on a re-armed engine -- other constants, other mode, other generator
+    seed than the run that parked it -- is bit for bit the run on a freshly created engine."""
+    N = 256
+
+    def run(kw, seed):
+        p = make(N, 40, 'fast', **kw)
+        p.seed = seed
+        s = chsimpy_amd.Solver(p)
+        s.prepare()
+        s.solve_or_resume(25)
+        sol = s.solve_or_resume(15)
+        out = (sol.U.copy(), sol.timedata.data().copy())
+        s.close()
+        return out
+    first = dict(full_sim=False, adaptive_time=True, delt_max=3e-9)
+    second = dict(full_sim=True, kappa_tilde=KAPPA * 1.3, delt=2e-11)
+    monkeypatch.setenv('CHS_ENGINE_POOL', '0')
+    fresh = run(second, 7)
+    monkeypatch.delenv('CHS_ENGINE_POOL')
+    run(first, 3)            # parks its engine on close
+    pooled = run(second, 7)  # ... which this run takes over
+    assert np.array_equal(pooled[0], fresh[0]) and np.array_equal(pooled[1], fresh[1])
+
+
 def test_simulator_update_every_drives_chunks(gpu, tmp_path):
     """Chunked driving (simulator.py:56-87): `update_every` steps per solve_or_resume, a host snapshot
     handed to the view hook after every chunk, the last chunk shortened to hit ntmax, and the
