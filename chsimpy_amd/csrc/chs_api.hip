@@ -237,8 +237,14 @@ extern "C" int chs_destroy(chs_handle h) {
   if (pool_enabled() && (size_t)E->N * E->N * E->esz <= CHS_POOL_FIELD_BYTES) {
     hipSetDevice(E->hc.device);
     if (hipStreamSynchronize(E->stream) == hipSuccess) {
-      std::lock_guard<std::mutex> lock(g_pool_mu);
-      if (g_pool.size() < CHS_POOL_MAX) { g_pool.push_back(E); return CHS_OK; }
+      Engine* oldest = nullptr;
+      {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        if (g_pool.size() >= CHS_POOL_MAX) { oldest = g_pool.front(); g_pool.erase(g_pool.begin()); }
+        g_pool.push_back(E);
+      }
+      free_engine(oldest);  // (the least recently parked one makes room)
+      return CHS_OK;
     }
   }
   free_engine(E);
