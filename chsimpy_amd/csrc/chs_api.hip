@@ -113,7 +113,9 @@ static DevState initial_state(const Engine* E) {
   return s0;
 }
 static void read_env_hooks(Engine* E) {
-  E->batchSteps = 1024;
+  // with a stop rule armed a call usually ends early: shorter batches, fewer launches issued behind the stop
+  // (a launch that finds the stop flag set costs ~2 us; the reference's default run stops at step 1674 of 1e6)
+  E->batchSteps = (!E->dc.full_sim || E->dc.time_limit_s > 0.0) ? 256 : 1024;
   if (const char* bs = getenv("CHS_BATCH_STEPS")) {  // test hook: small batches exercise the polling path
     const long v = atol(bs);
     if (v >= 1 && v <= CHS_ROWS_RING / 8) E->batchSteps = (int)v;
