@@ -78,6 +78,7 @@ static void free_engine(Engine* E) {
   if (E->engine == CHS_ENGINE_FAST) chs_fast_free(E);
   chs_pointwise_free(E);
   hipFree(E->dU); hipFree(E->dMU); hipFree(E->dT1); hipFree(E->dT2); hipFree(E->dHat);
+  if (E->dHat2) hipFree(E->dHat2);
   hipFree(E->dNoise); hipFree(E->dLambda); hipFree(E->dState); hipFree(E->dRows);
   for (auto e : E->timer.pool) hipEventDestroy(e);
   if (E->evA) hipEventDestroy(E->evA);
@@ -488,6 +489,8 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
     }
   }
   E->timer.on = profile;
+  E->dHatCall = E->dHat;  // (chs_fast_step may alternate two hat_U buffers from here on)
+  E->hatFlip = false;
   int64_t issued = 0, copied = 0;
   int batch = 0;
   bool stopped = false;
@@ -527,6 +530,15 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   CHS_HIP(hipEventElapsedTime(&ms, E->evA, E->evB));
   E->lastStepMs = ms;
   const DevState s = E->hState[0];
+  if (E->hatFlip) {
+    // two hat_U buffers alternated per ISSUED step; the one that holds the state behind the steps that were
+    // COMPLETED is the call's first one after an even number of them, the other one after an odd number
+    void* other = (E->dHat == E->dHatCall) ? E->dHat2 : E->dHat;
+    const bool even = ((s.rows_written < nsteps ? s.rows_written : nsteps) & 1) == 0;
+    void* valid = even ? E->dHatCall : other;
+    E->dHat2 = (valid == E->dHatCall) ? other : E->dHatCall;
+    E->dHat = valid;
+  }
   if (s.halt && s.stop_reason != CHS_STOP_NONE && !s.nan_flag && fused && !E->storeU && s.rows_written < nsteps) {
     // the energy rule or the time limit ended the call before its last step and the row kernel has
     // been keeping U in registers: hat_U is that of the last completed step, rebuild the field from

@@ -784,6 +784,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
   }
   T* hcol = hat + (size_t)kc * C::N;
+  // MODE_STEP with a second hat_U buffer (`nat`, chs_fast_step): the updated coefficients go there and the ones
+  // read stay what they were -- the state of the last completed step if the riding tail stops the run
+  T* hout = (MODE == MODE_STEP && nat != nullptr) ? nat + (size_t)kc * C::N : hcol;
   // constants of the spectral stage, requested here: their latency disappears behind the stage-in
   // (loaded where they are used they cost every workgroup ~4 K cycles of waiting)
   double lam1 = st->lam1, lam2 = st->lam2;  // (gated launches read them again behind the gate)
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       },
       [&](int pbase, const int*, T y[4], bool live) {
         if (live) {
-          T* hl = hcol + fc_opaque(l);
+          T* hl = hout + fc_opaque(l);
 #pragma unroll
           for (int t = 0; t < 4; ++t) hl[(size_t)(pbase + t) * C::G] = y[t];
         }
