@@ -256,31 +256,12 @@ extern "C" int chs_destroy(chs_handle h) {
 
 extern "C" int chs_engine(chs_handle h) { return h ? ((Engine*)h)->engine : CHS_EINVAL; }
 
-static int upload(Engine* E, void* dst, const double* src) {
-  const size_t n = (size_t)E->N * E->N;
-  if (E->dtype == CHS_F64) {
-    CHS_HIP(hipMemcpy(dst, src, n * 8, hipMemcpyHostToDevice));
-  } else {
-    std::vector<float> tmp(n);
-    for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
-    CHS_HIP(hipMemcpy(dst, tmp.data(), n * 4, hipMemcpyHostToDevice));
-  }
-  return CHS_OK;
-}
-// Field download through two pinned staging chunks: the DMA of chunk k+1 runs while the host copies (fp32: widens)
-// chunk k into the caller's pageable array -- a direct hipMemcpy into pageable memory took 2-44 ms for 32 MB.
-// The chunks belong to the process (one pair per device, allocated at the first download and kept: pinning
-// 16 MB costs milliseconds, an ensemble creates an engine per member); a mutex serialises the downloads.
 namespace {
 struct StagePair { void* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {}; };
 std::mutex g_stage_mu;
 std::map<int, StagePair> g_stage;  // by device
 }
-static int download(Engine* E, double* dst, const void* src) {
-  const size_t n = (size_t)E->N * E->N;
-  const size_t esz = E->esz;
-  CHS_HIP(hipStreamSynchronize(E->stream));
-  std::lock_guard<std::mutex> lock(g_stage_mu);
+static int stage_pair(Engine* E, StagePair** out) {
   StagePair& sp = g_stage[E->hc.device];
   if (!sp.buf[0]) {
     for (int i = 0; i < 2; ++i) {
@@ -288,6 +269,48 @@ static int download(Engine* E, double* dst, const void* src) {
       CHS_HIP(hipEventCreateWithFlags(&sp.ev[i], hipEventDisableTiming));
     }
   }
+  *out = &sp;
+  return CHS_OK;
+}
+// Field upload through the same two pinned chunks as the download below: the host fills (fp32: narrows) chunk k+1
+// while the DMA of chunk k runs.
+static int upload(Engine* E, void* dst, const double* src) {
+  const size_t n = (size_t)E->N * E->N;
+  const size_t esz = E->esz;
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  StagePair* sp = nullptr;
+  int rc = stage_pair(E, &sp);
+  if (rc) return rc;
+  const size_t per = CHS_STAGE_BYTES / esz;
+  const size_t nch = (n + per - 1) / per;
+  for (size_t k = 0; k < nch; ++k) {
+    const size_t o = k * per, cnt = (o + per <= n) ? per : n - o;
+    if (k >= 2) CHS_HIP(hipEventSynchronize(sp->ev[k & 1]));  // the copy that last used this chunk has finished
+    if (E->dtype == CHS_F64) {
+      memcpy(sp->buf[k & 1], src + o, cnt * 8);
+    } else {
+      float* f = (float*)sp->buf[k & 1];
+      for (size_t i = 0; i < cnt; ++i) f[i] = (float)src[o + i];
+    }
+    CHS_HIP(hipMemcpyAsync((char*)dst + o * esz, sp->buf[k & 1], cnt * esz, hipMemcpyHostToDevice, E->stream));
+    CHS_HIP(hipEventRecord(sp->ev[k & 1], E->stream));
+  }
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  return CHS_OK;
+}
+// Field download through two pinned staging chunks: the DMA of chunk k+1 runs while the host copies (fp32: widens)
+// chunk k into the caller's pageable array -- a direct hipMemcpy into pageable memory took 2-44 ms for 32 MB.
+// The chunks belong to the process (one pair per device, allocated at the first download and kept: pinning
+// 16 MB costs milliseconds, an ensemble creates an engine per member); a mutex serialises the downloads.
+static int download(Engine* E, double* dst, const void* src) {
+  const size_t n = (size_t)E->N * E->N;
+  const size_t esz = E->esz;
+  CHS_HIP(hipStreamSynchronize(E->stream));
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  StagePair* spp = nullptr;
+  const int rcs = stage_pair(E, &spp);
+  if (rcs) return rcs;
+  StagePair& sp = *spp;
   const size_t per = CHS_STAGE_BYTES / esz;  // elements per chunk
   const size_t nch = (n + per - 1) / per;
   auto issue = [&](size_t k) -> hipError_t {
