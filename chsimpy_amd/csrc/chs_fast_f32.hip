@@ -30,9 +30,19 @@ using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2
 #endif
 #if CHS_SMALL_E8_F32
 // (8 complex values per lane with radix-4 end passes, as in fp64: half the dependent instruction stream per lane)
-using G128 = FCfg<float, 128, 8, 256, 4, 4, 1, 4, 1, 0, 1, 2>;
-using G256 = FCfg<float, 256, 16, 256, 4, 8, 1, 4, 1, 0, 1, 2>;
-using G512 = FCfg<float, 512, 32, 256, 4, 4, 4, 4, 1, 1, 1, 2>;
+#ifndef CHS_T128_F32
+#define CHS_T128_F32 64
+#endif
+#ifndef CHS_T256_F32
+#define CHS_T256_F32 64
+#endif
+#ifndef CHS_T512_F32
+#define CHS_T512_F32 128
+#endif
+// (small workgroups as in fp64, chs_fast_f64.hip)
+using G128 = FCfg<float, 128, 8, CHS_T128_F32, 4, 4, 1, 4, 1, 0, 1, 2>;
+using G256 = FCfg<float, 256, 16, CHS_T256_F32, 4, 8, 1, 4, 1, 0, 1, 2>;
+using G512 = FCfg<float, 512, 32, CHS_T512_F32, 4, 4, 4, 4, 1, 1, 1, 2>;
 using G1024 = FCfg<float, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
 #else
 using G128 = FCfg<float, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;

@@ -11,9 +11,21 @@
 #define CHS_SMALL_E8 1
 #endif
 #if CHS_SMALL_E8
-using F128 = FCfg<double, 128, 8, 256, 4, 4, 1, 4, 1, 0, 1, 2>;
-using F256 = FCfg<double, 256, 16, 256, 4, 8, 1, 4, 1, 0, 1, 2>;
-using F512 = FCfg<double, 512, 32, 256, 4, 4, 4, 4, 1, 1, 1, 2>;
+// ... and small workgroups: the grid spreads over more CUs (N=512: 128 workgroups of 4 transforms instead of 64 of
+// 8) -- N=128 20.3 -> 16.1 us/step, N=256 21.3 -> 16.9, N=512 24.0 -> 20.8 on one box; N=1024 wants 256 threads
+// (37.5 us with 128, 32.1 with 256).
+#ifndef CHS_T128
+#define CHS_T128 64
+#endif
+#ifndef CHS_T256
+#define CHS_T256 64
+#endif
+#ifndef CHS_T512
+#define CHS_T512 128
+#endif
+using F128 = FCfg<double, 128, 8, CHS_T128, 4, 4, 1, 4, 1, 0, 1, 2>;
+using F256 = FCfg<double, 256, 16, CHS_T256, 4, 8, 1, 4, 1, 0, 1, 2>;
+using F512 = FCfg<double, 512, 32, CHS_T512, 4, 4, 4, 4, 1, 1, 1, 2>;
 using F1024 = FCfg<double, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
 #else
 using F128 = FCfg<double, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
