@@ -13,7 +13,8 @@
 #if CHS_SMALL_E8
 // ... and small workgroups: the grid spreads over more CUs (N=512: 128 workgroups of 4 transforms instead of 64 of
 // 8) -- N=128 20.3 -> 16.1 us/step, N=256 21.3 -> 16.9, N=512 24.0 -> 20.8 on one box; N=1024 wants 256 threads
-// (37.5 us with 128, 32.1 with 256).
+// (37.5 us with 128, 32.1 with 256), and so does N=2048 (128 threads there mean 2-column tiles, 16-byte pieces
+// for the row kernels: 87.7 instead of 59.3 us).
 #ifndef CHS_T128
 #define CHS_T128 64
 #endif
@@ -35,6 +36,7 @@ using F1024 = FCfg<double, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
 using F128 = FCfg<double, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
 using F256 = FCfg<double, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
 using F512 = FCfg<double, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
+using F512C = F512;
 using F1024 = FCfg<double, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
 #endif
 #ifndef CHS_F2048_E8
