@@ -235,7 +235,7 @@ static bool fused_adaptive(const Engine* E) {
   return E->dc.adaptive_time && E->fusedAdapt && E->dPartColRows != nullptr;
 }
 static bool can_skip_u(const Engine* E) {
-  return (!E->dc.adaptive_time || fused_adaptive(E)) && !CHS_ALWAYS_STORE_U;
+  return !E->dc.adaptive_time || fused_adaptive(E);
 }
 
 int chs_fast_step(Engine* E, bool first, bool last) {
@@ -294,7 +294,7 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   // Stop rules armed (energy rule, time limit) or an adaptive time step: the bookkeeping still rides in the
   // next k_col, whose other workgroups wait for its decision in front of their first global write (gated
   // tail, gate_wait) -- no 14 us one-block launch per step.  A run being profiled keeps the separate launch.
-  const bool gate = !defer && !E->timer.on && E->partSet[0][0] != nullptr && CHS_GATED_TAIL;
+  const bool gate = !defer && !E->timer.on && E->partSet[0][0] != nullptr;
   if (last || (!defer && !gate)) return chs_launch_step_tail(E, last ? 0 : 1);
   E->tailDeferred = true;
   E->tailGated = gate;

@@ -203,10 +203,6 @@ __device__ __forceinline__ void cmul(T& r, T& i, T wr, T wi) {
 
 template <typename T>
 __device__ __forceinline__ void ldc(const T* __restrict__ tab, int idx, T& r, T& i) {
-#ifdef CHS_DIAG_NOTW  // timing experiment only (wrong results): what the twiddle loads cost
-  r = T(0.7) + T(idx) * T(1e-9); i = T(0.3);
-  return;
-#endif
   if constexpr (sizeof(T) == 8) {
     const double2 v = *reinterpret_cast<const double2*>(tab + 2 * (size_t)idx);
     r = v.x; i = v.y;

@@ -25,35 +25,14 @@ using G8192C = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS,
 using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, CHS_F32_CT>;
 using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, CHS_F32_CT>;
 // fp32 below N = 4096: the shapes of the fp64 configurations (groups inside one wavefront)
-#ifndef CHS_SMALL_E8_F32
-#define CHS_SMALL_E8_F32 1
-#endif
-#if CHS_SMALL_E8_F32
-// (8 complex values per lane with radix-4 end passes, as in fp64: half the dependent instruction stream per lane)
-#ifndef CHS_T128_F32
-#define CHS_T128_F32 64
-#endif
-#ifndef CHS_T256_F32
-#define CHS_T256_F32 64
-#endif
-#ifndef CHS_T512_F32
-#define CHS_T512_F32 128
-#endif
-// (small workgroups as in fp64, chs_fast_f64.hip)
-using G128 = FCfg<float, 128, 8, CHS_T128_F32, 4, 4, 1, 4, 1, 0, 1, 2>;
-using G256 = FCfg<float, 256, 16, CHS_T256_F32, 4, 8, 1, 4, 1, 0, 1, 2>;
-using G512 = FCfg<float, 512, 32, CHS_T512_F32, 4, 4, 4, 4, 1, 1, 1, 2>;
+// (8 complex values per lane with radix-4 end passes and small workgroups, as in fp64: chs_fast_f64.hip)
+using G128 = FCfg<float, 128, 8, 64, 4, 4, 1, 4, 1, 0, 1, 2>;
+using G256 = FCfg<float, 256, 16, 64, 4, 8, 1, 4, 1, 0, 1, 2>;
+using G512 = FCfg<float, 512, 32, 128, 4, 4, 4, 4, 1, 1, 1, 2>;
 using G1024 = FCfg<float, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
 // N=512: k_col in smaller workgroups than the row kernels (two of a tile's four columns), as in fp64: 18.0 -> 17.2 us
 // (N=1024 the same way, both types: no gain)
 using G512C = FCfg<float, 512, 32, 64, 4, 4, 4, 4, 1, 1, 1, 2, 4>;
-#else
-using G128 = FCfg<float, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
-using G256 = FCfg<float, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
-using G512 = FCfg<float, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
-using G1024 = FCfg<float, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
-using G512C = G512;
-#endif
 #ifndef CHS_F32_CT_SMALL
 #define CHS_F32_CT_SMALL 8  // N = 2048 fp32: 8 columns per tile (32-byte row pieces; +7 % against 4)
 #endif

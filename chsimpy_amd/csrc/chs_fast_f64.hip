@@ -7,49 +7,19 @@
 // Small grids are bound by one workgroup life per launch (a handful of workgroups, nothing to overlap
 // with): 8 complex values per lane instead of 16 -- radix-4 end passes -- halve the dependent
 // instruction stream of a lane and double the number of workgroups (CHS_SMALL_E8).
-#ifndef CHS_SMALL_E8
-#define CHS_SMALL_E8 1
-#endif
-#if CHS_SMALL_E8
 // ... and small workgroups: the grid spreads over more CUs (N=512: 128 workgroups of 4 transforms instead of 64 of
 // 8) -- N=128 20.3 -> 16.1 us/step, N=256 21.3 -> 16.9, N=512 24.0 -> 20.8 on one box; N=1024 wants 256 threads
 // (37.5 us with 128, 32.1 with 256), and so does N=2048 (128 threads there mean 2-column tiles, 16-byte pieces
 // for the row kernels: 87.7 instead of 59.3 us).
-#ifndef CHS_T128
-#define CHS_T128 64
-#endif
-#ifndef CHS_T256
-#define CHS_T256 64
-#endif
-#ifndef CHS_T512
-#define CHS_T512 128
-#endif
-using F128 = FCfg<double, 128, 8, CHS_T128, 4, 4, 1, 4, 1, 0, 1, 2>;
-using F256 = FCfg<double, 256, 16, CHS_T256, 4, 8, 1, 4, 1, 0, 1, 2>;
-using F512 = FCfg<double, 512, 32, CHS_T512, 4, 4, 4, 4, 1, 1, 1, 2>;
-#ifndef CHS_T512C
-#define CHS_T512C 64   // k_col likes two transforms per workgroup, the row kernels four (13.1 / 12.7 us against 14.3 / 15.3)
-#endif
-using F512C = FCfg<double, 512, 32, CHS_T512C, 4, 4, 4, 4, 1, 1, 1, 2, 4>;  // (two of the 4 columns of a tile)
+using F128 = FCfg<double, 128, 8, 64, 4, 4, 1, 4, 1, 0, 1, 2>;
+using F256 = FCfg<double, 256, 16, 64, 4, 8, 1, 4, 1, 0, 1, 2>;
+using F512 = FCfg<double, 512, 32, 128, 4, 4, 4, 4, 1, 1, 1, 2>;
+// k_col likes two transforms per workgroup (two of the 4 columns of a tile), the row kernels four (13.1 / 12.7 us against 14.3 / 15.3)
+using F512C = FCfg<double, 512, 32, 64, 4, 4, 4, 4, 1, 1, 1, 2, 4>;
 using F1024 = FCfg<double, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
-#else
-using F128 = FCfg<double, 128, 4, 256, 8, 1, 1, 8, 0, 0, 1, 2>;
-using F256 = FCfg<double, 256, 8, 256, 8, 2, 1, 8, 1, 0, 1, 2>;
-using F512 = FCfg<double, 512, 16, 256, 8, 4, 1, 8, 1, 0, 1, 2>;
-using F512C = F512;
-using F1024 = FCfg<double, 1024, 32, 256, 8, 8, 1, 8, 2, 0, 8, 2>;
-#endif
-#ifndef CHS_F2048_E8
-#define CHS_F2048_E8 0
-#endif
-#if CHS_F2048_E8
-// two wavefronts per transform, 8 complex values per lane: twice the workgroups (the ensemble size)
-using F2048 = FCfg<double, 2048, 128, 256, 4, 8, 8, 4, 2, 1, 8, 4, 4>;
-using F2048C = FCfg<double, 2048, 128, 256, 4, 8, 8, 4, 2, 1, 8, 2, 4>;
-#else
+// N = 2048: 16 complex values per lane (an 8-per-lane variant with two wavefronts per transform measured equal)
 using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 using F2048C = F2048;
-#endif
 // N = 4096: two wavefronts per transform, 16 complex values per lane, four radix passes
 #ifndef CHS_ROW_WPS
 #define CHS_ROW_WPS 4

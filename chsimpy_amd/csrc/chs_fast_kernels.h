@@ -108,18 +108,12 @@ __device__ __forceinline__ int row_of_block(int b) {
 // instead of 32 (tools/ubench/strided_rows.hip: the access pattern alone 84 -> 40 us at N=4096 fp64).  Measured on
 // the kernels: N=8192 fp64 row 481 -> 435 us (+3 % steps/s), fp32 332 -> 322 us; N=4096 fp64 row -2 % but k_col
 // behind it +4 % (net -0.8 %), so it is on from CHS_ROW_INTERLEAVE_MIN_N upwards only.
-#ifndef CHS_ROW_INTERLEAVE
-#define CHS_ROW_INTERLEAVE 1
-#endif
-#ifndef CHS_TAIL_LAST
-#define CHS_TAIL_LAST 1
-#endif
 #ifndef CHS_ROW_INTERLEAVE_MIN_N
 #define CHS_ROW_INTERLEAVE_MIN_N 8192
 #endif
 template <class C>
 __device__ __forceinline__ void row_lane_map(int& l, int& sub) {
-  if constexpr ((CHS_ROW_INTERLEAVE != 0) && C::C == 2 && (C::G % 64 == 0) && C::N >= CHS_ROW_INTERLEAVE_MIN_N) {
+  if constexpr (C::C == 2 && (C::G % 64 == 0) && C::N >= CHS_ROW_INTERLEAVE_MIN_N) {
     const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
     sub = ln >> 5;
     l = w * 32 + (ln & 31);
@@ -152,80 +146,12 @@ __device__ __forceinline__ void store4(T* p, const T q[4]) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 
-// Start-up stagger (experiment knob): every second workgroup of an XCD sleeps for
-// CHS_STAGGER x ~3.5 us before its first load, so that the memory phase of one half overlaps the
-// compute phase of the other (a kernel here has only 2-4 rounds of workgroups: no steady state).
-#ifndef CHS_STAGGER_UNIT
-#define CHS_STAGGER_UNIT 127
-#endif
-#ifndef CHS_STAGGER_ROW
-#define CHS_STAGGER_ROW 0
-#endif
-#ifndef CHS_STAGGER_COL
-#define CHS_STAGGER_COL 0
-#endif
-template <int NSLEEP>
-__device__ __forceinline__ void stagger_start() {
-  if constexpr (NSLEEP > 0) {
-    // Delay every other workgroup of an XCD's dispatch order (j = blockIdx / 8), flipped every 32:
-    // whether the dispatcher fills a CU first (j, j+1) or deals across the 32 CUs first (j, j+32),
-    // the two residents of a CU start half a phase apart and keep that offset round after round.
-    const int j = blockIdx.x >> 3;
-    if ((j ^ (j >> 5)) & 1) {
-#pragma unroll 1
-      for (int i = 0; i < NSLEEP; ++i) __builtin_amdgcn_s_sleep(CHS_STAGGER_UNIT);  // 64 cycles per unit
-    }
-  }
-}
-
-// ---- diagnostic build only (-DCHS_STAMPS): s_memtime stamps at the phase boundaries of the
-// row and column kernels, first wave of every workgroup; read back with chs_debug_stamps().
-// The stamp values go to a buffer nothing else reads; no output is computed from them.
-#ifndef CHS_ALWAYS_STORE_U
-#define CHS_ALWAYS_STORE_U 0  // 1: write U to HBM on every step even when nothing can read it
-#endif
+// Build knobs that remain (everything else that was tried is recorded with its measurement in DESIGN.md section 7):
 #ifndef CHS_ALIAS_T
-#define CHS_ALIAS_T 1
+#define CHS_ALIAS_T 1     // T2 overwrites T1 in place (one array less in the per-step working set)
 #endif
 #ifndef CHS_COL_ZIGZAG
-#define CHS_COL_ZIGZAG 1
-#endif
-#ifndef CHS_LOG_TABLE
-#define CHS_LOG_TABLE 1  // table-driven log in the fused row kernel's pointwise part (0: division-based)
-#endif
-#ifndef CHS_COL_H0
-#define CHS_COL_H0 0  // 1: hat_U of slot 0 requested before the forward passes (measured neutral)
-#endif
-#ifndef CHS_COL_TW_LDS
-#define CHS_COL_TW_LDS 1  // k_col<MODE_STEP>: radix-pass twiddles from LDS
-#endif
-#ifndef CHS_ROW_LDS_PAD
-#define CHS_ROW_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower the row kernels' occupancy
-#endif
-#ifndef CHS_ROW_TW_LDS
-#define CHS_ROW_TW_LDS 0  // fused row kernel: middle-pass twiddles from LDS (needs CHS_ROW_PADL=4 to keep 4 workgroups per CU)
-#endif
-// ---- k_col<MODE_STEP> build knobs (the defaults are what measured best at N=4096 fp64, tools/ab.sh)
-#ifndef CHS_COL_PARK
-#define CHS_COL_PARK 0     // 1: park the lane's hat_U column in LDS early instead of fetching it slot by slot (equal)
-#endif
-#ifndef CHS_COL_PRELOAD
-#define CHS_COL_PRELOAD 3  // 3: the second half of the tile is requested behind the first half's LDS writes (its latency runs under the first half's quad reads); 1: at the start of the second round; 2: the whole tile up front (more registers)
-#endif
-#ifndef CHS_COL_LDS_PAD
-#define CHS_COL_LDS_PAD 0  // diagnostic: extra dynamic LDS to lower k_col's occupancy
-#endif
-#ifndef CHS_COL_DIRECT
-#define CHS_COL_DIRECT 0  // 1: k_col takes its tile rows straight into the quads of the lanes (half-wave swaps, no LDS staging): measured 8 % slower
-#endif
-#ifndef CHS_GATED_TAIL
-#define CHS_GATED_TAIL 1  // 0: modes that can stop a call early run the bookkeeping as a kernel of its own per step
-#endif
-#ifndef CHS_COL_PIPE
-#define CHS_COL_PIPE 1     // recombine<PIPE>: 1 = next slot's loads ahead of this slot's stores, 2 = a slot earlier
-#endif
-#ifndef CHS_ROW_PIPE
-#define CHS_ROW_PIPE false
+#define CHS_COL_ZIGZAG 1  // k_col walks the tiles in alternating direction from step to step (Infinity Cache)
 #endif
 
 // Returns x through an opaque asm so that index arithmetic derived from it is not CSE'd
@@ -237,24 +163,6 @@ __device__ __forceinline__ int launder(int x) {
   // the index maps are made of compile to signed sequences (4-5 instructions instead of one shift)
   __builtin_assume(x >= 0 && x < 1024);
   return x;
-}
-
-// a's upper half-wave <-> b's lower half-wave (v_permlane32_swap_b32, two per double): k_col's direct
-// tile access (below) pairs lane i (one column) with lane i+32 (the neighbouring column)
-__device__ __forceinline__ void swap_halves(double& a, double& b) {
-  const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
-  const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
-  const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-  const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-  a = __hiloint2double((int)r1[0], (int)r0[0]);
-  b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-__device__ __forceinline__ void swap_halves(float&, float&) {}  // (direct tile access is an fp64 path)
-
-// elements of the middle-pass twiddle tables twa | twb (contiguous, build_tables): what the fused row kernel can afford in LDS
-template <class C>
-constexpr int row_tw_elems() {
-  return 2 * ((C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
 }
 
 // ---------------------------------------------------------------------------
@@ -293,20 +201,15 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
     // EnergieEut in the shared-log form of the fused row kernel (log U - log(1-U) from the table-driven log:
     // no division, no spills at four waves per SIMD; the division-based chs_mu needed 204 bytes of scratch here)
     double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
-    if constexpr (CHS_LOG_TABLE && sizeof(T) == 8) {
+    if constexpr (sizeof(T) == 8) {
       for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
       __syncthreads();
     }
     unsigned dom = 0;
     auto mu = [&](T& u) {
-      T m;
-      if constexpr (CHS_LOG_TABLE) {
-        const T uinv = T(1) - u;
-        const T lU = chs_log_unit_tab<T>(u, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
-        m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
-      } else {
-        m = chs_mu<T>(u, RT, BRT, A0, A1);
-      }
+      const T uinv = T(1) - u;
+      const T lU = chs_log_unit_tab<T>(u, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
+      const T m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
       s2 += (double)m * (double)m;
       u = m;
       asm volatile("" : "+v"(u), "+v"(s2), "+v"(dom));  // one grid point at a time (register pressure)
@@ -352,7 +255,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
   const int row = row_of_block<C>(blockIdx.x) + sub;
   T* scr = lds + (size_t)sub * C::SCR;
   double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
-  if constexpr (CHS_LOG_TABLE && sizeof(T) == 8) {
+  if constexpr (sizeof(T) == 8) {
     for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
     __syncthreads();
   }
@@ -378,13 +281,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
     if (pass == 1) {
       auto mu = [&](T& u) {
         const T uinv = T(1) - u;
-        T m;
-        if constexpr (CHS_LOG_TABLE) {
-          const T lU = chs_log_unit_tab<T>(u, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
-          m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
-        } else {
-          m = chs_mu<T>(u, RT, BRT, A0, A1);
-        }
+        const T lU = chs_log_unit_tab<T>(u, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
+        const T m = chs_mu_from_logs_fast<T>(u, uinv, lU, lV, RT, BRT, A0, A1);
         s2 += (double)m * (double)m;
         u = m;
         asm volatile("" : "+v"(u), "+v"(s2), "+v"(dom));  // one grid point at a time (register pressure)
@@ -418,12 +316,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
 //         166-175, sharing log U and log(1-U) with the energy density), sum(mu^2), and
 //         the forward row DCT-II into T1 -- U is never re-read from HBM.
 // ---------------------------------------------------------------------------
-#ifndef CHS_LB_FUSED
-#define CHS_LB_FUSED 2
-#endif
-#ifndef CHS_LB_COL
-#define CHS_LB_COL 2
-#endif
 template <class C, bool DIAG, bool FUSE, bool ADAPT = false>
 __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C::T* __restrict__ T2, typename C::T* __restrict__ U,
                                                     typename C::T* __restrict__ T1, FTables<typename C::T> tb,
@@ -437,25 +329,12 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   int l, sub;
   row_lane_map<C>(l, sub);
-  if constexpr (DIAG && FUSE) stagger_start<CHS_STAGGER_ROW>();
   const double mean_u = st->meanU;  // requested at entry (k_col of this step wrote it), used in the pointwise part
   // reduction table of the table-driven log, behind the exchange scratch (visible after the first barrier)
   double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
-  if constexpr (DIAG && CHS_LOG_TABLE && sizeof(T) == 8) {
+  if constexpr (DIAG && sizeof(T) == 8) {
     for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
     if constexpr (C::WAVE_LOCAL) __syncthreads();  // (no block barrier before the pointwise part otherwise)
-  }
-  // middle-pass twiddles (twa | twb) from LDS where the row kernel has room for them (CHS_ROW_TW_LDS)
-  FTables<T> tbp = tb;
-  if constexpr (DIAG && FUSE && CHS_ROW_TW_LDS && !C::WAVE_LOCAL) {
-    T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0));
-    constexpr int NTW = row_tw_elems<C>();
-    for (int i = 2 * threadIdx.x; i < NTW; i += 2 * C::THREADS) {
-      if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(ltw + i) = *reinterpret_cast<const double2*>(tb.twa + i);
-      else *reinterpret_cast<float2*>(ltw + i) = *reinterpret_cast<const float2*>(tb.twa + i);
-    }
-    tbp.twa = ltw;
-    tbp.twb = ltw + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
   }
   const int row0 = row_of_block<C>(blockIdx.x);
   const int row = row0 + sub;
@@ -468,7 +347,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     for (int t = 0; t < 4; ++t) y[t] = *at_boff(T2, tile_boff<C>(row, idx[t]));
   }, [](int, const int*, T*, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
-  inv_passes<C>(re, im, scr, tbp, launder(l));
+  inv_passes<C>(re, im, scr, tb, launder(l));
   if constexpr (DIAG && FUSE) STAMP(0, 2);
   __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
   const unsigned urow = (unsigned)row * C::N;
@@ -539,16 +418,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     unsigned dom = 0;
     auto point = [&](T& u) {
       const T uinv = T(1) - u;
-      T lU, lV;
-#ifdef CHS_DIAG_NOLOG  // timing experiment only (wrong results): what the two logarithms cost
-      lU = u; lV = uinv;
-#else
-      if constexpr (CHS_LOG_TABLE) { lU = chs_log_unit_tab<T>(u, ltab, dom); lV = chs_log_unit_tab<T>(uinv, ltab, dom); }
-      else {
-        dom = max(dom, ((u > T(0)) && (uinv > T(0))) ? 0u : ~0u);
-        lU = chs_log_pos<T>(u); lV = chs_log_pos<T>(uinv);
-      }
-#endif
+      const T lU = chs_log_unit_tab<T>(u, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
       sE += (double)chs_energy_from_logs_fast<T>(u, uinv, lU, lV, RT, B, A0, A1);
       sPS += fabs((double)u - mean);
       cSA += ((double)u < thr) ? 1 : 0;
@@ -624,11 +494,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   if constexpr (DIAG && FUSE) STAMP(0, 4);
   if constexpr (FUSE) {
     __builtin_amdgcn_sched_barrier(0);
-    fwd_passes<C>(re, im, scr, tbp, launder(l));
+    fwd_passes<C>(re, im, scr, tb, launder(l));
     if constexpr (DIAG && FUSE) STAMP(0, 5);
     __builtin_amdgcn_sched_barrier(0);
-    // (CHS_ROW_PIPE: twiddles of the next slot ahead of this slot's stores -- measured slower here)
-    recombine<C, true, false, CHS_ROW_PIPE>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
+    recombine<C, true, false, false>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
                               [](int, const int*, T*, bool, NoFetch) {},
                               [&](int, const int idx[4], T y[4], bool live) {
       if (live) {
@@ -714,19 +583,18 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   } else {
     if (st->halt) return;
   }
-  if constexpr (MODE == MODE_STEP) stagger_start<CHS_STAGGER_COL>();
   if constexpr (MODE == MODE_STEP) STAMP(1, 0);
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
   int bid = blockIdx.x;
   if constexpr (MODE == MODE_STEP) {
-    // one extra workgroup, dispatched FIRST (block 0) so that its short chain of dependent loads runs
-    // under the first wave of tiles instead of trailing the kernel: the record of the PREVIOUS step
-    // and this step's time bookkeeping (chs_fast_step), instead of a launch of its own
-    // Deferred tail (nobody waits for it, ta.gate == 0): the LAST block instead.  The tiles are a whole number of
-    // rounds of workgroups; an extra workgroup at the front pushes its slot's tiles back by its own duration and
-    // the kernel ends that much later, at the back it fills the gap the first slot to finish leaves (CHS_TAIL_LAST).
+    // One extra workgroup carries the record of the PREVIOUS step and this step's time bookkeeping
+    // (chs_fast_step) instead of a launch of its own.  Gated (somebody waits for its decision): block 0,
+    // dispatched first, so that its short chain of dependent loads runs under the first wave of tiles.
+    // Deferred (nobody waits, ta.gate == 0): the LAST block -- the tiles are a whole number of rounds of
+    // workgroups; an extra workgroup at the front pushes its slot's tiles back by its own duration, at the back
+    // it fills the gap the first slot to finish leaves.
     if (ta.enabled) {
-      const bool at_end = (CHS_TAIL_LAST != 0) && !ta.gate;
+      const bool at_end = !ta.gate;
       if (bid == (at_end ? (int)gridDim.x - 1 : 0)) {
         step_tail_body<C::THREADS>(ta, st, reinterpret_cast<double*>(chs_dyn_lds));
         return;
@@ -734,23 +602,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       if (!at_end) bid -= 1;
     }
   }
-  // Direct tile access (fp64, two of a tile's four columns per workgroup, groups of whole wavefronts): a
-  // wavefront holds 32 lanes of EACH of the two columns -- lane i the first, lane i+32 the second, same
-  // butterfly index -- so that the 4 rows x 2 columns a pair of lanes needs are four 16-byte pieces of one
-  // 128-byte line: each lane loads two of them and one half-wave swap per register hands the neighbour its
-  // column.  No LDS staging, no staging barriers; HBM still sees 16-byte pieces at a 32-byte pitch, like
-  // the staged path (the other half of every 32 bytes belongs to the sibling workgroup of the tile).
-  constexpr bool DIRECT = (CHS_COL_DIRECT != 0) && sizeof(T) == 8 && C::C == 2 && C::CT == 4 && (C::G % 64 == 0) &&
-                          (CHS_COL_PARK == 0) && (CHS_COL_H0 == 0);
-  int l, sub;
-  if constexpr (DIRECT) {
-    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    sub = ln >> 5;
-    l = w * 32 + (ln & 31);
-  } else {
-    l = threadIdx.x % C::G;
-    sub = threadIdx.x / C::G;
-  }
+  const int l = threadIdx.x % C::G, sub = threadIdx.x / C::G;
   // tile and the part of it this workgroup owns; the Q workgroups of a tile get block numbers
   // b, b+8, ...: same XCD under round-robin dispatch (speed only, see row_of_block)
   int ct, hh;
@@ -772,8 +624,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // behind the barriers of the stage-in): no L2 round trip per pass, and no load that would have to
   // wait behind the hat_U stores at the start of the inverse passes
   FTables<T> tbp = tb;
-  if constexpr (MODE == MODE_STEP && CHS_COL_TW_LDS) {
-    T* ltw = lds + col_lds_elems<C>() + (CHS_COL_PARK ? C::E * C::THREADS : 0);
+  if constexpr (MODE == MODE_STEP) {
+    T* ltw = lds + col_lds_elems<C>();
     constexpr int NTW = col_tw_elems<C>();
     for (int i = 2 * threadIdx.x; i < NTW; i += 2 * C::THREADS) {
       if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(ltw + i) = *reinterpret_cast<const double2*>(tb.tw0 + i);
@@ -791,67 +643,25 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // (loaded where they are used they cost every workgroup ~4 K cycles of waiting)
   double lam1 = st->lam1, lam2 = st->lam2;  // (gated launches read them again behind the gate)
   // (the column index is wave-uniform when a group fills whole wavefronts: scalar loads, no VGPRs)
-  const int kc_u = (C::G >= 64 && !DIRECT) ? __builtin_amdgcn_readfirstlane(kc) : kc;
+  const int kc_u = (C::G >= 64) ? __builtin_amdgcn_readfirstlane(kc) : kc;
   const double lc = lam[kc_u];
   const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc_u + 1] : 0.0;
-  // What the spectral stage reads per recombination slot (4 positions of this lane): {lambda_kr,
-  // sin^2(pi kr/N)} from the table (L2), fetched one slot ahead, and hat_U.  The lane's 2E values of
-  // hat_U are parked in LDS long before they are needed (every lane reads back only what it wrote,
-  // so no barrier guards the parking slots themselves):
-  //   positions 0..E-1   requested with the tile at kernel entry -> hpark1 (its own LDS area)
-  //   positions E..2E-1  requested after the forward passes      -> hpark2 = the exchange scratch,
-  //                      idle until the inverse passes
-  struct Fetched { double2 ls[4]; T h[(CHS_COL_PARK != 0) ? 1 : 4]; };
-  // hat_U of positions 0..3 -- the first slot of every lane and the special lane's own slot --
-  // requested before the forward passes (CHS_COL_H0): nothing waits for it at the start of the stage
-  constexpr bool H0 = (MODE == MODE_STEP) && (CHS_COL_H0 != 0) && (CHS_COL_PARK == 0);
-  T h0[4] = {T(0), T(0), T(0), T(0)};
+  // What the spectral stage reads per recombination slot (4 positions of this lane), fetched one slot
+  // ahead: {lambda_kr, sin^2(pi kr/N)} from the table (L2) and hat_U.
+  struct Fetched { double2 ls[4]; T h[4]; };
   auto fetch = [&](int pbase, const int idx[4]) {
     Fetched p;
 #pragma unroll
     for (int t = 0; t < 4; ++t) p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];
-    if constexpr (CHS_COL_PARK == 0) {
-      if (H0 && pbase == 0) {  // (compile-time after inlining)
+    const T* hl = hcol + fc_opaque(l);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) p.h[t] = h0[t];
-      } else {
-        const T* hl = hcol + fc_opaque(l);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) p.h[t] = hl[(size_t)(pbase + t) * C::G];
-      }
-    }
+    for (int t = 0; t < 4; ++t) p.h[t] = hl[(size_t)(pbase + t) * C::G];
     return p;
   };
-  constexpr bool PARK = (MODE == MODE_STEP) && (CHS_COL_PARK != 0);
-  T* hpark1 = lds + col_lds_elems<C>() + threadIdx.x;
-  T* hpark2 = lds + threadIdx.x;
-  T hearly[PARK ? C::E : 1];
   if constexpr (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE) {
-    if constexpr (DIRECT) {
-      // ---- tile rows -> quads, straight from HBM/L2 into the registers of the transform
-      const T* tile = Tin + (size_t)ct * C::N * C::CT + hh * C::C;
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-        for (int j = 0; j < C::R0 / 2; ++j) {
-          // rows 4m .. 4m+3 of the quad: this lane fetches rows 4m + 2 sub and 4m + 2 sub + 1, both columns
-          const T* p1 = tile + (size_t)(4 * (m1 + C::L1 * j) + 2 * sub) * C::CT;
-          const T* p2 = tile + (size_t)(4 * (m2 + C::L1 * j) + 2 * sub) * C::CT;
-          const double2 x1 = *reinterpret_cast<const double2*>(p1), y1 = *reinterpret_cast<const double2*>(p1 + C::CT);
-          const double2 x2 = *reinterpret_cast<const double2*>(p2), y2 = *reinterpret_cast<const double2*>(p2 + C::CT);
-          T q1[4] = {x1.x, y1.x, x1.y, y1.y}, q2[4] = {x2.x, y2.x, x2.y, y2.y};
-          // (x.x, x.y) = (column 0, column 1) of one row: the swap leaves row 4m (+1) of the lane's own column
-          // in .x and row 4m+2 (+3) in .y, in both half-waves
-          swap_halves(q1[0], q1[2]); swap_halves(q1[1], q1[3]);
-          swap_halves(q2[0], q2[2]); swap_halves(q2[1], q2[3]);
-          pack_quads<C>(q1, q2, q, j, re, im);
-        }
-      }
-      __syncthreads();  // (the pass twiddles copied to LDS above are visible from here on)
-    } else {
-    // ---- stage in: tile rows -> quads of this group's column.  The whole tile is requested
-    // first (one HBM latency for both rounds), then it passes through LDS half by half.
+    // ---- stage in: tile rows -> quads of this group's column.  The first half is requested at once, the
+    // second as soon as the first has left its registers (its latency runs under the first half's barrier
+    // and quad reads); both pass through LDS half by half.
     const T* tile = Tin + (size_t)ct * C::N * C::CT;
     constexpr int PER = CS::PER;
     constexpr int PW = CS::PW;
@@ -873,17 +683,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       }
     };
     request(0);
-    if constexpr (CHS_COL_PRELOAD == 2) request(1);
-    if constexpr (PARK) {
-#pragma unroll
-      for (int p = 0; p < C::E; ++p) hearly[p] = hcol[(size_t)p * C::G + l];
-    }
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
       __syncthreads();
-      if constexpr (CHS_COL_PRELOAD == 1) {
-        if (rho == 1) request(1);
-      }
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int f = PW * (threadIdx.x + i * C::THREADS);
@@ -891,11 +693,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         lds[lo] = stage[rho][PW * i];
         if constexpr (PW == 2) lds[lo + 1] = stage[rho][2 * i + 1];
       }
-      if constexpr (CHS_COL_PRELOAD == 3) {
-        // the second half is requested as soon as the first has left its registers: its latency runs under
-        // the first half's barrier and quad reads instead of in front of the second half's LDS writes
-        if (rho == 0) request(1);
-      }
+      if (rho == 0) request(1);
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < C::NP0; ++q) {
@@ -914,16 +712,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       }
     }
     __syncthreads();
-    }
     if constexpr (MODE == MODE_STEP) STAMP(1, 1);
-    if constexpr (PARK) {
-#pragma unroll
-      for (int p = 0; p < C::E; ++p) hpark1[p * C::THREADS] = hearly[p];
-    }
-    if constexpr (H0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) h0[t] = hcol[(size_t)t * C::G + l];
-    }
     fwd_passes<C>(re, im, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 2);
     if constexpr (MODE == MODE_STEP) {
@@ -935,14 +724,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         if (gate_wait(st, ta.seq, lam1, lam2)) return;
       }
     }
-    if constexpr (PARK) {
-      __syncthreads();  // every wavefront has read its last exchange: the scratch is free
-      T hlate[C::E];
-#pragma unroll
-      for (int p = 0; p < C::E; ++p) hlate[p] = hcol[(size_t)(C::E + p) * C::G + l];
-#pragma unroll
-      for (int p = 0; p < C::E; ++p) hpark2[p * C::THREADS] = hlate[p];
-    }
   }
 
   // ---- recombination / spectral stage / adjoint recombination, in place per slot
@@ -951,18 +732,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   constexpr bool FWD = (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE);
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL || MODE == MODE_INV_NATIVE);
   if constexpr (MODE == MODE_STEP) {
-    recombine<C, true, true, CHS_COL_PIPE>(re, im, tb, l, fetch,
+    recombine<C, true, true, true>(re, im, tb, l, fetch,
       [&](int pbase, const int*, T y[4], bool live, const Fetched& p) {
-        T hold[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int pos = pbase + t;  // compile-time after unrolling
-          if constexpr (PARK) hold[t] = (pos < C::E) ? hpark1[pos * C::THREADS] : hpark2[(pos - C::E) * C::THREADS];
-          else hold[t] = p.h[t];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const T h = chs_spectral<T, (C::N >= CHS_F32_SPECTRAL_MIN_N)>(hold[t], y[t], p.ls[t].x, lc, lam1, lam2);
+          const T h = chs_spectral<T, (C::N >= CHS_F32_SPECTRAL_MIN_N)>(p.h[t], y[t], p.ls[t].x, lc, lam1, lam2);
           y[t] = h;
           const double term = (double)h * (double)h * (p.ls[t].y + sqc);
           e2 += live ? term : 0.0;
@@ -1002,33 +776,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   }
   if constexpr (MODE == MODE_STEP) STAMP(1, 3);
   if constexpr (ADJ) {
-    // wave-local groups exchange behind wavefront fences only: the parked hat_U of another
-    // wavefront may lie in this group's scratch, so everybody must be through the spectral stage
-    if constexpr (PARK && C::WAVE_LOCAL) __syncthreads();
     inv_passes<C>(re, im, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 4);
     // ---- stage out: quads -> tile rows
-    if constexpr (DIRECT) {
-      T* tile = Tout + (size_t)ct * C::N * C::CT + hh * C::C;
-#pragma unroll
-      for (int q = 0; q < C::NP0; ++q) {
-        const int ld = launder(l);
-        const int m1 = ld + C::G * q, m2 = C::L1 - 1 - m1;
-#pragma unroll
-        for (int j = 0; j < C::R0 / 2; ++j) {
-          T q1[4], q2[4];
-          unpack_quads<C>(re, im, q, j, q1, q2);
-          swap_halves(q1[0], q1[2]); swap_halves(q1[1], q1[3]);   // back to (column 0, column 1) of two rows
-          swap_halves(q2[0], q2[2]); swap_halves(q2[1], q2[3]);
-          T* p1 = tile + (size_t)(4 * (m1 + C::L1 * j) + 2 * sub) * C::CT;
-          T* p2 = tile + (size_t)(4 * (m2 + C::L1 * j) + 2 * sub) * C::CT;
-          *reinterpret_cast<double2*>(p1) = make_double2(q1[0], q1[2]);
-          *reinterpret_cast<double2*>(p1 + C::CT) = make_double2(q1[1], q1[3]);
-          *reinterpret_cast<double2*>(p2) = make_double2(q2[0], q2[2]);
-          *reinterpret_cast<double2*>(p2 + C::CT) = make_double2(q2[1], q2[3]);
-        }
-      }
-    } else {
     T* tile = Tout + (size_t)ct * C::N * C::CT;
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
@@ -1064,7 +814,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
           else *reinterpret_cast<float2*>(dst) = make_float2(a, b);
         }
       }
-    }
     }
   }
   if constexpr (MODE == MODE_STEP) {
@@ -1105,13 +854,11 @@ static FTables<T> get_tables(Engine* E) {
 template <class C, class CC = C>
 struct Launch {
   using T = typename C::T;
-  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + (CHS_LOG_TABLE ? CHS_LOGTAB_N * 16 : 0) +
-                                    (CHS_ROW_TW_LDS ? (size_t)row_tw_elems<C>() * sizeof(T) : 0) + CHS_ROW_LDS_PAD;
+  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16;
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
   static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && (C::R0 % 4 == 0);
-  // + the parking area of half a hat_U column per lane (k_col<MODE_STEP>)
-  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (CHS_COL_PARK ? (size_t)CC::E * CC::THREADS : 0) +
-                                     (CHS_COL_TW_LDS ? (size_t)col_tw_elems<CC>() : 0)) * sizeof(T) + CHS_COL_LDS_PAD;
+  // staging / exchange scratch + the pass twiddles (k_col<MODE_STEP>)
+  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (size_t)col_tw_elems<CC>()) * sizeof(T);
   static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
 
   template <class K>

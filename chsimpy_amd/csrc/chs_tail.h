@@ -48,11 +48,7 @@ __device__ __forceinline__ void fin_update(const DevConsts& dc, DevState* st, do
   }
   st->rows_written = k + 1;
   const double L2v = st->L2_cur, tp = st->time_passed;
-#ifdef CHS_DIAG_NOHALT  // timing experiments with deliberately wrong kernels: keep stepping through NaNs
-  if (false) {
-#else
   if (E != E || E2 != E2 || Ra != Ra || PS != PS || L2v != L2v || tp != tp || SA != SA) {
-#endif
     st->nan_flag = 1;  // timedata.py:10 fires before computed_steps += 1
     st->halt = 1;
   } else {
