@@ -46,8 +46,13 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=0, help='0 = size the CPU sample automatically')
     ap.add_argument('--profile-steps', type=int, default=20)
     ap.add_argument('--energy-stop', action='store_true', help='full_sim=False (the reference default: stop at the E2 maximum); not the headline workload')
-    ap.add_argument('--rederive-hat', action='store_true', help='recompute hat_U = dctn(U) on entry of the timed call (the literal '
-                    'solver.py:159) instead of continuing the device loop of the warm-up call')
+    ap.add_argument('--continue-loop', action='store_true', help='the timed call continues the device loop of the warm-up call '
+                    '(hat_U carried, last call of the run) instead of entering through hat_U = dctn(U) as every '
+                    'solve_or_resume call of the reference does (solver.py:159); not the default protocol')
+    ap.add_argument('--ensemble-baseline', action='store_true', help='configs[4] beside its CPU comparator: P oracle processes '
+                    '(one run each, experiment.py:197-216) against the GPU ensemble at N=2048; prints one JSON line')
+    ap.add_argument('--ens-procs', type=int, default=0, help='CPU processes of --ensemble-baseline (0 = the cores this process may use, at most 16)')
+    ap.add_argument('--ens-steps', type=int, default=0, help='timesteps per CPU member and repetition (0 = sized to ~5 s)')
     ap.add_argument('--dry-run', action='store_true', help='launcher/collective rehearsal without device work (CPU tests of the '
                     'N>1 path); the line it prints is marked as such and is not a measurement')
     a = ap.parse_args()
@@ -82,24 +87,103 @@ SLOT_TRANSFERS = {
 }
 
 
-def cpu_baseline(N, steps_hint):
-    """The oracle (numpy/scipy restatement, 1 core like chsimpy/simulator.py:14,36) on a
-    bounded sample of the same workload, timed like examples/benchmark.py:68-76."""
+def time_repetitions(run_once, warmups=1, repetitions=3):
+    """The timing protocol of examples/benchmark.py:25-27,68-76: `warmups` untimed runs, then `repetitions`
+    timed ones (each = prepare(), then the wall clock around the solve); returns the list of times."""
+    for _ in range(warmups):
+        run_once()
+    return [run_once() for _ in range(repetitions)]
+
+
+def _oracle_member(args):
+    """One CPU run of the oracle: prepare(), then the wall clock around solve_or_resume (a worker process of the
+    ensemble comparator, or the single-core baseline)."""
+    N, steps, fac = args
     from threadpoolctl import threadpool_limits
     from oracle import chs_oracle as orc
     with threadpool_limits(limits=1, user_api='blas'):
-        # size the sample: ~0.09 us per grid point per step (measured on the GPU box host) on one core
-        est = 0.09e-6 * N * N
-        steps = steps_hint or int(max(2, min(200, 20.0 / est)))
-        p = orc.make_params(N, steps + 1)
-        o = orc.OracleSolver(p)
+        kw = {}
+        if fac is not None:
+            kw = dict(func_A0=lambda T, f=fac[0]: orc.A0(T) * f, func_A1=lambda T, f=fac[1]: orc.A1(T) * f)
+        o = orc.OracleSolver(orc.make_params(N, steps + 1, **kw))
         o.prepare()
         t0 = time.time()
         o.solve_or_resume()
-        dt = time.time() - t0
-    return {'value': steps / dt, 'unit': 'timesteps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'oracle/chs_oracle.py (numpy+scipy.fftpack), N={N} fp64, {steps} timesteps after prepare(), '
-                      f'{dt:.1f} s wall, BLAS limited to 1 thread; host has {os.cpu_count()} logical cores'}
+        return time.time() - t0
+
+
+def cpu_baseline(N, steps_hint):
+    """The oracle (numpy/scipy restatement, 1 core like chsimpy/simulator.py:14,36) on a bounded sample of the
+    same workload, timed like examples/benchmark.py:68-76: 1 warm-up + 3 repetitions of prepare() + solve."""
+    # size the sample: ~0.09 us per grid point per step on one core (measured on the GPU box host); four runs in ~20 s
+    est = 0.09e-6 * N * N
+    steps = steps_hint or int(max(2, min(200, 5.0 / est)))
+    times = time_repetitions(lambda: _oracle_member((N, steps, None)))
+    mean = sum(times) / len(times)
+    return {'value': steps / mean, 'unit': 'timesteps/s', 'cores': 1, 'kind': 'port',
+            'best': steps / min(times), 'repetitions': len(times), 'warmups': 1,
+            'sample': f'oracle/chs_oracle.py (numpy+scipy.fftpack), N={N} fp64, {steps} timesteps after prepare() per run, '
+                      f'1 warm-up + {len(times)} timed runs (mean {mean:.1f} s, min {min(times):.1f} s), BLAS limited to 1 thread; '
+                      f'host has {os.cpu_count()} logical cores'}
+
+
+def ensemble_baseline(a):
+    """BASELINE.json configs[4] beside its CPU comparator: the reference runs one member per
+    physical core in a process pool (experiment.py:197-216); here P processes of the oracle, one N=2048 member
+    each with its own (A0, A1) factors, 1 warm-up + 3 repetitions (examples/benchmark.py:68-76), against the GPU
+    ensemble on one MI355X (members run `concurrent` at a time, chsimpy_amd/experiment.py)."""
+    import multiprocessing as mp
+    N = 2048
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    P = a.ens_procs or max(1, min(allowed, 16))
+    steps = a.ens_steps or 6
+    fac = np.random.Generator(np.random.PCG64(85972)).uniform(0.995, 1.005, size=(64, 2))
+    ctx = mp.get_context('fork')   # as the reference's pool (experiment.py:16,211); nothing here has touched the GPU yet
+    with ctx.Pool(P) as pool:
+        def run_once():
+            t0 = time.time()
+            pool.map(_oracle_member, [(N, steps, tuple(fac[i % 64])) for i in range(P)])
+            return time.time() - t0
+        times = time_repetitions(run_once)
+    mean = sum(times) / len(times)
+    cpu = {'value': P * steps / mean, 'best': P * steps / min(times), 'unit': 'timesteps/s (aggregate)', 'cores': P,
+           'kind': 'port', 'per_member_steps_per_s': steps / mean,
+           'sample': f'{P} oracle processes (fork pool, BLAS 1 thread each), one N={N} fp64 member of {steps} timesteps each, '
+                     f'1 warm-up + {len(times)} timed repetitions: mean {mean:.2f} s, min {min(times):.2f} s; '
+                     f'{allowed} cores allowed to this process, host has {os.cpu_count()} logical cores'}
+    out = {'metric': 'ensemble timesteps/s at N=2048 fp64 (BASELINE.json configs[4] members)', 'cpu_ensemble': cpu}
+    if not a.dry_run:
+        import __graft_entry__ as g
+        g.build_hip()
+        import chsimpy_amd
+        from chsimpy_amd import experiment as ex
+        gpu = {}
+        runs, nt = 8, 400
+        for conc in (1, 3):
+            def run_once(conc=conc):
+                p = chsimpy_amd.Parameters()
+                p.N, p.ntmax, p.full_sim, p.kappa_tilde, p.file_id = N, nt, True, KAPPA, '/tmp/chs_ens'
+                ep = ex.ExperimentParams()
+                ep.runs = runs
+                t0 = time.time()
+                ex.run_ensemble(p, ep, run_fn=lambda i, pp, rv, al: ex.run_experiment_gpu(i, pp, rv, al, None, postprocess=False),
+                                concurrent=conc)
+                return time.time() - t0
+            t = time_repetitions(run_once)
+            gpu[f'concurrent_{conc}'] = {'value': runs * (nt - 1) / (sum(t) / len(t)), 'best': runs * (nt - 1) / min(t),
+                                        'unit': 'timesteps/s (aggregate, one MI355X)',
+                                        'sample': f'{runs} members x {nt - 1} timesteps end to end (engine from the pool, start field drawn '
+                                                  f'on the device, no sympy post-processing), 1 warm-up + {len(t)} repetitions'}
+        out['gpu_ensemble'] = gpu
+        best = max(v['value'] for v in gpu.values())
+        out['gpu_over_cpu'] = best / cpu['value']
+        out['roofline_note'] = (f'{best:.0f} steps/s x {algorithmic_bytes_per_step(N, 8) / 1e6:.1f} MB algorithmic = '
+                                f'{best * algorithmic_bytes_per_step(N, 8) / 1e12:.2f} TB/s; a member (T + hat_U = 64 MiB) lives in the '
+                                f'256 MiB Infinity Cache, so this is on-die bandwidth, not HBM')
+    print(json.dumps(out), flush=True)
 
 
 def dry_run(a, rank, world, dist, coll_dev):
@@ -148,31 +232,64 @@ def launch_ranks(a):
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
-    procs = []
+    import tempfile
+    procs, outs = [], []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        outs.append(tempfile.TemporaryFile(mode='w+'))  # every rank's stdout is kept (a file: no pipe to fill up)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    line = [ln for ln in (out0 or '').splitlines() if ln.startswith('{')]
-    if any(codes) or not line:
-        sys.stderr.write(f'bench.py: ranks exited with {codes}\n')
-        if out0:
-            sys.stderr.write(out0)
+                                      stdout=outs[-1], text=True))
+    # Poll all ranks: the first one to fail ends the run (its siblings would otherwise sit in the rendezvous or a
+    # barrier until the collective's own timeout), and the whole launch is bounded.
+    deadline = time.time() + float(os.environ.get('CHS_BENCH_LAUNCH_TIMEOUT', '1500'))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad:
+            failed = f'rank {bad[0]} exited with {procs[bad[0]].returncode}'
+        elif time.time() > deadline:
+            failed = 'timeout'
+        else:
+            time.sleep(0.05)
+    if failed is not None:
+        for p in procs:          # our own children, by handle
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    codes = [p.returncode for p in procs]
+    texts = []
+    for f in outs:
+        f.seek(0)
+        texts.append(f.read())
+        f.close()
+    line = [ln for ln in texts[0].splitlines() if ln.startswith('{')]
+    if failed is not None or any(codes) or not line:
+        sys.stderr.write(f'bench.py: {failed or "a rank failed"}; ranks exited with {codes}\n')
+        for r, t in enumerate(texts):
+            if t:
+                sys.stderr.write(f'--- stdout of rank {r} ---\n{t}')
         sys.exit(1)
     print(line[-1], flush=True)
 
 
 def main():
     a = parse()
+    if a.ensemble_baseline:
+        return ensemble_baseline(a)
     if a.gpus > 1 and 'RANK' not in os.environ:
         return launch_ranks(a)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('CHS_BENCH_TEST_DIE_RANK') == str(rank) and world > 1:
+        sys.exit(3)  # test hook (tests/test_bench_launch.py): a rank that dies before the rendezvous
     if world != a.gpus and world > 1:
         a.gpus = world
     dist = None
@@ -230,18 +347,30 @@ def main():
     rows_w, rc_w = eng.step_n(a.warmup)
     nocheck = os.environ.get('CHS_BENCH_NOCHECK') == '1'  # timing experiments with deliberately wrong kernels (tools/ab.sh)
     assert nocheck or (rc_w == 0 and rows_w.shape[0] == a.warmup)
-    # keep the input resident: nothing is uploaded inside the timed region.  The timed call is the last call of
-    # the run and continues the device loop of the warm-up call, as Solver.solve_or_resume does between the
-    # chunks of a run: hat_U stays on the device instead of being recomputed as dctn(idctn(hat_U)) at the call
-    # boundary (solver.py:159; --rederive-hat times the literal recomputation).
+    # keep the input resident: nothing is uploaded inside the timed region.  The timed call is one
+    # solve_or_resume call of the reference, literally: it enters through hat_U = dctn(U) (solver.py:159), runs
+    # `steps` complete timesteps and leaves U in HBM (solver.py:251).  --continue-loop times the engine's own
+    # mode for the chunks of one run instead (hat_U carried across the call boundary, last call of the run);
+    # its figure is reported beside the headline either way (config.other_protocol_ms_per_step).
+    literal = dict(rederive_hat=True, last_call=False)
+    carried = dict(rederive_hat=False, last_call=True)
     sync()
     t0 = time.perf_counter()
-    rows, rc = eng.step_n(a.steps, rederive_hat=a.rederive_hat, last_call=True)
+    rows, rc = eng.step_n(a.steps, **(carried if a.continue_loop else literal))
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     assert nocheck or (rows.shape[0] == a.steps and rc == 0), (rows.shape, rc)
     dt = t1 - t0
     dev_ms = eng.last_step_ms()
+    # the other protocol, right behind the timed region (same clocks), for the record
+    other_ms = None
+    if world == 1:
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        rows_o, rc_o = eng.step_n(a.steps, **(literal if a.continue_loop else carried))
+        torch.cuda.synchronize()
+        other_ms = (time.perf_counter() - t2) * 1e3 / a.steps
+        assert nocheck or (rows_o.shape[0] == a.steps and rc_o == 0)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -301,8 +430,11 @@ def main():
                        'ensemble': f'{world} independent run(s), one per GPU' if world > 1 else 'single run',
                        'device_ms_per_step': round(dev_ms / a.steps, 5),
                        'untimed_steps_before_timed_region': max(a.warmup, PREWARM),
-                       'call_entry': 'hat_U = dctn(U) recomputed on entry (solver.py:159)' if a.rederive_hat else
-                                     'continues the device loop of the warm-up call (hat_U resident)'},
+                       'call_entry': 'continues the device loop of the warm-up call (hat_U resident, last call of the run)'
+                                     if a.continue_loop else
+                                     'one literal solve_or_resume call: hat_U = dctn(U) recomputed on entry (solver.py:159), U stored at the end (251)',
+                       'other_protocol': 'literal solve_or_resume call' if a.continue_loop else 'continuing the device loop (hat_U carried)',
+                       'other_protocol_ms_per_step': None if other_ms is None else round(other_ms, 5)},
             'roofline': roofline,
             'energies_last_step': energies,
         }

@@ -4,7 +4,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -86,6 +85,10 @@ static void free_engine(Engine* E) {
   for (int i = 0; i < 4; ++i) if (E->evPoll[i]) hipEventDestroy(E->evPoll[i]);
   if (E->hState) hipHostFree(E->hState);
   if (E->hRows) hipHostFree(E->hRows);
+  for (int i = 0; i < 2; ++i) {
+    if (E->stageBuf[i]) hipHostFree(E->stageBuf[i]);
+    if (E->stageEv[i]) hipEventDestroy(E->stageEv[i]);
+  }
   if (E->stream) hipStreamDestroy(E->stream);
   delete E;
 }
@@ -130,10 +133,28 @@ static void read_env_hooks(Engine* E) {
 // written before they are read in a run.  CHS_ENGINE_POOL=0 switches it off.
 #define CHS_POOL_MAX 4
 #define CHS_POOL_FIELD_BYTES ((size_t)160 << 20)
+#define CHS_POOL_TOTAL_BYTES ((size_t)3 << 30)  // device memory the parked engines may hold together
 namespace {
 std::mutex g_pool_mu;
 std::vector<Engine*> g_pool;
 bool pool_enabled() { const char* e = getenv("CHS_ENGINE_POOL"); return !(e && e[0] == '0'); }
+// device bytes of an engine, to the accuracy the cap needs: its field-sized arrays (U, MU, T1, T2, hat_U [, the second
+// hat_U of the small grids' stop-rule runs, the adaptive step's partial rows])
+size_t engine_bytes(const Engine* E) {
+  const size_t nb = (size_t)E->N * E->N * E->esz;
+  return nb * (5 + (E->dHat2 ? 1 : 0) + (E->dNoise ? 1 : 0)) + (E->dPartColRows ? (size_t)E->nRowBlocks * E->N * 8 : 0);
+}
+}
+// Frees every parked engine (the process's only library-owned state besides the handles): for a caller that
+// is done with a device, and registered by the Python binding to run at interpreter exit.
+extern "C" int chs_pool_clear(void) {
+  std::vector<Engine*> all;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    all.swap(g_pool);
+  }
+  for (Engine* E : all) free_engine(E);
+  return CHS_OK;
 }
 static int rearm(Engine* E, const chs_consts* c) {
   fill_consts(E, c);
@@ -240,13 +261,20 @@ extern "C" int chs_destroy(chs_handle h) {
   if (pool_enabled() && (size_t)E->N * E->N * E->esz <= CHS_POOL_FIELD_BYTES) {
     hipSetDevice(E->hc.device);
     if (hipStreamSynchronize(E->stream) == hipSuccess) {
-      Engine* oldest = nullptr;
+      std::vector<Engine*> evicted;
       {
         std::lock_guard<std::mutex> lock(g_pool_mu);
-        if (g_pool.size() >= CHS_POOL_MAX) { oldest = g_pool.front(); g_pool.erase(g_pool.begin()); }
         g_pool.push_back(E);
+        // the least recently parked ones make room: at most CHS_POOL_MAX engines, CHS_POOL_TOTAL_BYTES together
+        size_t total = 0;
+        for (const Engine* Q : g_pool) total += engine_bytes(Q);
+        while (g_pool.size() > 1 && (g_pool.size() > CHS_POOL_MAX || total > CHS_POOL_TOTAL_BYTES)) {
+          total -= engine_bytes(g_pool.front());
+          evicted.push_back(g_pool.front());
+          g_pool.erase(g_pool.begin());
+        }
       }
-      free_engine(oldest);  // (the least recently parked one makes room)
+      for (Engine* Q : evicted) free_engine(Q);
       return CHS_OK;
     }
   }
@@ -256,20 +284,16 @@ extern "C" int chs_destroy(chs_handle h) {
 
 extern "C" int chs_engine(chs_handle h) { return h ? ((Engine*)h)->engine : CHS_EINVAL; }
 
-namespace {
-struct StagePair { void* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {}; };
-std::mutex g_stage_mu;
-std::map<int, StagePair> g_stage;  // by device
-}
-static int stage_pair(Engine* E, StagePair** out) {
-  StagePair& sp = g_stage[E->hc.device];
-  if (!sp.buf[0]) {
+// The two pinned staging chunks of a handle (allocated at its first transfer and kept with it -- a parked engine
+// keeps them too: pinning 16 MB costs milliseconds, an ensemble creates an engine per member).  Per handle, so
+// that concurrent members of an ensemble move their fields at the same time.
+static int stage_pair(Engine* E) {
+  if (!E->stageBuf[0]) {
     for (int i = 0; i < 2; ++i) {
-      CHS_HIP(hipHostMalloc(&sp.buf[i], CHS_STAGE_BYTES, hipHostMallocDefault));
-      CHS_HIP(hipEventCreateWithFlags(&sp.ev[i], hipEventDisableTiming));
+      CHS_HIP(hipHostMalloc(&E->stageBuf[i], CHS_STAGE_BYTES, hipHostMallocDefault));
+      CHS_HIP(hipEventCreateWithFlags(&E->stageEv[i], hipEventDisableTiming));
     }
   }
-  *out = &sp;
   return CHS_OK;
 }
 // Field upload through the same two pinned chunks as the download below: the host fills (fp32: narrows) chunk k+1
@@ -277,57 +301,50 @@ static int stage_pair(Engine* E, StagePair** out) {
 static int upload(Engine* E, void* dst, const double* src) {
   const size_t n = (size_t)E->N * E->N;
   const size_t esz = E->esz;
-  std::lock_guard<std::mutex> lock(g_stage_mu);
-  StagePair* sp = nullptr;
-  int rc = stage_pair(E, &sp);
+  int rc = stage_pair(E);
   if (rc) return rc;
   const size_t per = CHS_STAGE_BYTES / esz;
   const size_t nch = (n + per - 1) / per;
   for (size_t k = 0; k < nch; ++k) {
     const size_t o = k * per, cnt = (o + per <= n) ? per : n - o;
-    if (k >= 2) CHS_HIP(hipEventSynchronize(sp->ev[k & 1]));  // the copy that last used this chunk has finished
+    if (k >= 2) CHS_HIP(hipEventSynchronize(E->stageEv[k & 1]));  // the copy that last used this chunk has finished
     if (E->dtype == CHS_F64) {
-      memcpy(sp->buf[k & 1], src + o, cnt * 8);
+      memcpy(E->stageBuf[k & 1], src + o, cnt * 8);
     } else {
-      float* f = (float*)sp->buf[k & 1];
+      float* f = (float*)E->stageBuf[k & 1];
       for (size_t i = 0; i < cnt; ++i) f[i] = (float)src[o + i];
     }
-    CHS_HIP(hipMemcpyAsync((char*)dst + o * esz, sp->buf[k & 1], cnt * esz, hipMemcpyHostToDevice, E->stream));
-    CHS_HIP(hipEventRecord(sp->ev[k & 1], E->stream));
+    CHS_HIP(hipMemcpyAsync((char*)dst + o * esz, E->stageBuf[k & 1], cnt * esz, hipMemcpyHostToDevice, E->stream));
+    CHS_HIP(hipEventRecord(E->stageEv[k & 1], E->stream));
   }
   CHS_HIP(hipStreamSynchronize(E->stream));
   return CHS_OK;
 }
 // Field download through two pinned staging chunks: the DMA of chunk k+1 runs while the host copies (fp32: widens)
 // chunk k into the caller's pageable array -- a direct hipMemcpy into pageable memory took 2-44 ms for 32 MB.
-// The chunks belong to the process (one pair per device, allocated at the first download and kept: pinning
-// 16 MB costs milliseconds, an ensemble creates an engine per member); a mutex serialises the downloads.
 static int download(Engine* E, double* dst, const void* src) {
   const size_t n = (size_t)E->N * E->N;
   const size_t esz = E->esz;
   CHS_HIP(hipStreamSynchronize(E->stream));
-  std::lock_guard<std::mutex> lock(g_stage_mu);
-  StagePair* spp = nullptr;
-  const int rcs = stage_pair(E, &spp);
+  const int rcs = stage_pair(E);
   if (rcs) return rcs;
-  StagePair& sp = *spp;
   const size_t per = CHS_STAGE_BYTES / esz;  // elements per chunk
   const size_t nch = (n + per - 1) / per;
   auto issue = [&](size_t k) -> hipError_t {
     const size_t o = k * per, cnt = (o + per <= n) ? per : n - o;
-    hipError_t e = hipMemcpyAsync(sp.buf[k & 1], (const char*)src + o * esz, cnt * esz, hipMemcpyDeviceToHost, E->stream);
+    hipError_t e = hipMemcpyAsync(E->stageBuf[k & 1], (const char*)src + o * esz, cnt * esz, hipMemcpyDeviceToHost, E->stream);
     if (e != hipSuccess) return e;
-    return hipEventRecord(sp.ev[k & 1], E->stream);
+    return hipEventRecord(E->stageEv[k & 1], E->stream);
   };
   CHS_HIP(issue(0));
   for (size_t k = 0; k < nch; ++k) {
     if (k + 1 < nch) CHS_HIP(issue(k + 1));
-    CHS_HIP(hipEventSynchronize(sp.ev[k & 1]));
+    CHS_HIP(hipEventSynchronize(E->stageEv[k & 1]));
     const size_t o = k * per, cnt = (o + per <= n) ? per : n - o;
     if (E->dtype == CHS_F64) {
-      memcpy(dst + o, sp.buf[k & 1], cnt * 8);
+      memcpy(dst + o, E->stageBuf[k & 1], cnt * 8);
     } else {
-      const float* f = (const float*)sp.buf[k & 1];
+      const float* f = (const float*)E->stageBuf[k & 1];
       for (size_t i = 0; i < cnt; ++i) dst[o + i] = (double)f[i];
     }
   }
@@ -476,6 +493,10 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   if (nsteps < 0) nsteps = 0;
   CHS_HIP(hipSetDevice(E->hc.device));
   E->stateCached = false;
+  {
+    const char* gw = getenv("CHS_TEST_GATE_WITHHOLD");  // test hook: provoke the gate's timeout path
+    E->testGateWithhold = gw && gw[0] == '1';
+  }
   int rc;
   if ((rc = ensure_rows(E))) return rc;
   if (profile) {
@@ -553,6 +574,16 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   CHS_HIP(hipEventElapsedTime(&ms, E->evA, E->evB));
   E->lastStepMs = ms;
   const DevState s = E->hState[0];
+  if (s.gate_timeout) {
+    // A workgroup gave up waiting for the riding bookkeeping (never seen outside the test hook): the call's
+    // remaining kernels were no-ops, the loop's device state is not that of a completed step.  The handle stays
+    // usable: the next call enters through hat_U = dctn(U) of whatever field it is given (chs_set_U / chs_prepare).
+    E->hat_valid = false; E->resident = false; E->stateCached = false;
+    E->tailDeferred = false; E->tailGated = false;
+    if (steps_done) *steps_done = 0;
+    chs_set_error("internal: a workgroup gave up waiting for the step's bookkeeping (gated tail)");
+    return CHS_EHIP;
+  }
   if (E->hatFlip) {
     // two hat_U buffers alternated per ISSUED step; the one that holds the state behind the steps that were
     // COMPLETED is the call's first one after an even number of them, the other one after an odd number
@@ -587,10 +618,6 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   if (rows) {
     // solver.py:230 `domtime = self.time_passed ** (1 / 3)` with the host libm
     for (int64_t i = 0; i < done; ++i) rows[i * 9 + 4] = pow(rows[i * 9 + 4], 1.0 / 3.0);
-  }
-  if (s.gate_timeout) {
-    chs_set_error("internal: a workgroup gave up waiting for the step's bookkeeping (gated tail)");
-    return CHS_EHIP;
   }
   if (s.nan_flag) {
     chs_set_error("NaN in a recorded scalar (timedata.py:10): U left (0,1)");

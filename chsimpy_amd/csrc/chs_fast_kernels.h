@@ -721,7 +721,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       // decision here: stopped -> leave hat_U, T and the partial sums as the previous step left them
       // (run_steps rebuilds U from hat_U); otherwise take this step's coefficients from it.
       if (ta.gate) {
-        if (gate_wait(st, ta.seq, lam1, lam2)) return;
+        if (gate_wait(st, ta.seq, ta.gate_spins, red, lam1, lam2)) return;
       }
     }
   }
@@ -935,7 +935,10 @@ struct Launch {
         if (E->tailDeferred) {
           ta = chs_tail_args(E, E->tailSet, 1);
           g = grid + 1;
-          if (E->tailGated) { ta.gate = 1; ta.seq = ++E->gateSeq; }
+          if (E->tailGated) {
+            ta.gate = 1; ta.seq = ++E->gateSeq;
+            if (E->testGateWithhold) { ta.withhold = 1; ta.gate_spins = 1 << 10; }
+          }
         } else if (E->preRider) {
           ta = chs_tail_args(E, -1, 1);
           ta.pre_only = 1;

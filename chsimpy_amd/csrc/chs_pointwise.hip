@@ -85,7 +85,7 @@ __global__ __launch_bounds__(PW_THREADS) void k_pre(DevConsts dc, DevState* __re
 // ---------------------------------------------------------------------------
 __global__ void k_call_begin(DevConsts dc, DevState* __restrict__ st) {
 #pragma clang fp contract(off)
-  st->halt = 0; st->nan_flag = 0; st->rows_written = 0;
+  st->halt = 0; st->nan_flag = 0; st->rows_written = 0; st->gate_timeout = 0;
   st->delt_coef = dc.delt0;
   const double lam1 = dc.delt0 / dc.delx2;
   st->lam1 = lam1;

@@ -77,6 +77,8 @@ struct TailArgs {
   int enabled = 0, do_pre = 0;
   int gate = 0;                   // publish the decision to the other workgroups of the carrying k_col launch
   unsigned long long seq = 0;     // ... under this sequence number (DevState::decided)
+  int gate_spins = 1 << 20;       // polls (s_sleep 16 between them, ~1 us each) before a waiting workgroup gives up
+  int withhold = 0;               // test hook (CHS_TEST_GATE_WITHHOLD): the decision is never published
   int pre_only = 0;  // first step of a call: no record yet, only the time-step control of the coming step
   int reverse = 0;  // (k_col rider, not a tail input) walk the column tiles in descending order this step
   DevConsts dc;
@@ -235,10 +237,15 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
     st->computed_steps = loc.computed_steps; st->rows_written = loc.rows_written;
     st->skip_check = loc.skip_check; st->stop_reason = loc.stop_reason; st->nan_flag = loc.nan_flag;
     st->halt = loc.halt;
-    if (ta.gate) {
+    if (ta.gate && !ta.withhold) {
       // everything above becomes visible at agent scope before the sequence number does: the waiting
-      // workgroups (any CU, any XCD) read halt / lam1 / lam2 with agent-scope loads behind it
+      // workgroups (any CU, any XCD) read halt / lam1 / lam2 with agent-scope (L1-bypassing) loads behind it.
+      // The explicit waits stand on both sides of the write-back: the state stores have left this wavefront
+      // before it starts, and it has completed before the flag goes out (hipcc may drop the fence's own wait
+      // when it can prove the wavefront's vmcnt scoreboard empty, cdna_hip_programming.md Guideline 16).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(&st->decided, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -247,24 +254,39 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
 // The other side of the gate: called by every thread of a workgroup of the carrying k_col launch in front of
 // its first global write.  Returns the published halt flag and the coefficients of this step.  One lane
 // polls (the bookkeeping workgroup is block 0, dispatched first, and waits for nobody: it always gets
-// there; by the time a tile workgroup has staged and transformed its tile it has long finished), bounded.
-__device__ __forceinline__ int gate_wait(DevState* __restrict__ st, unsigned long long seq, double& lam1, double& lam2) {
+// there; by the time a tile workgroup has staged and transformed its tile it has long finished), bounded:
+// a workgroup that gives up raises gate_timeout AND halt, so that every later kernel of the call is a no-op
+// and the call ends with an error instead of stepping on with a column pass that did not happen.
+// Ordering (MI355X_MICROARCH.md, inter-workgroup visibility): the producer wrote the state with plain stores,
+// drained them, released at agent scope and then stored the sequence number.  The consumer's polling lane reads
+// the payload itself, after its poll has matched, with agent-scope loads that bypass this CU's L1 (sc1) -- the
+// measured-valid form that spares the L1 invalidate an acquire fence would cost the co-resident workgroup; the
+// compiler barrier keeps those loads behind the poll in program order (a wavefront's loads return in order).
+// The other wavefronts get the values through LDS behind the workgroup barrier.  `box` = 4 doubles of LDS.
+__device__ __forceinline__ int gate_wait(DevState* __restrict__ st, unsigned long long seq, int spins, double* box,
+                                         double& lam1, double& lam2) {
   if (threadIdx.x == 0) {
-    int it = 0;
+    int it = 0, tmo = 0;
     while (__hip_atomic_load(&st->decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
       __builtin_amdgcn_s_sleep(16);
-      if (++it > (1 << 20)) {  // ~1 s: cannot happen unless block 0 never ran; stop instead of hanging the device
-        st->gate_timeout = 1;
+      // (a sibling that has already given up spares the others the full wait)
+      if (++it > spins || ((it & 63) == 0 && __hip_atomic_load(&st->gate_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        tmo = 1;
+        __hip_atomic_store(&st->gate_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->halt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
     }
+    asm volatile("" ::: "memory");
+    const int halt = __hip_atomic_load(&st->halt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    box[0] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&st->lam1), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+    box[1] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&st->lam2), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+    box[2] = (halt | tmo) ? 1.0 : 0.0;
   }
   __syncthreads();
-  const int halt = __hip_atomic_load(&st->halt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int tmo = __hip_atomic_load(&st->gate_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  lam1 = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&st->lam1), __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT));
-  lam2 = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&st->lam2), __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT));
-  return halt | tmo;
+  lam1 = box[0];
+  lam2 = box[1];
+  return box[2] != 0.0;
 }

@@ -112,19 +112,22 @@ def run_experiment_gpu(run_id, init_params, rand_values, A_list, U_init=None, po
     from .simulator import Simulator
     params, fac_A0, fac_A1 = run_params(init_params, run_id, rand_values, A_list)
     simulator = Simulator(params, U_init)
-    solution = simulator.solve()
-    simulator.export()
-    ca = cb = sa = sb = float('nan')
-    if postprocess:
-        # experiment.py:110-112 -- a failure here (sympy missing, no common tangent, not exactly two
-        # spinodal roots) is an error of the run, as in the reference: a silent NaN would poison
-        # -results-agg.csv.  postprocess=False skips the thermodynamic columns explicitly.
-        with _SYMPY_LOCK:
-            cgap = utils.get_miscibility_gap(params.R, params.temp, params.B, solution.A0, solution.A1)
-            ca, cb = float(cgap[0]), float(cgap[1])
-            sa, sb = (float(r) for r in utils.get_roots_of_EPP(params.R, params.temp, solution.A0, solution.A1))
-    itargmax = int(np.argmax(solution.E2))
-    simulator.solver.close(fetch_U=False)   # the record needs scalars only
+    try:
+        solution = simulator.solve()
+        simulator.export()
+        ca = cb = sa = sb = float('nan')
+        if postprocess:
+            # experiment.py:110-112 -- a failure here (sympy missing, no common tangent, not exactly two
+            # spinodal roots) is an error of the run, as in the reference: a silent NaN would poison
+            # -results-agg.csv.  postprocess=False skips the thermodynamic columns explicitly.
+            with _SYMPY_LOCK:
+                cgap = utils.get_miscibility_gap(params.R, params.temp, params.B, solution.A0, solution.A1)
+                ca, cb = float(cgap[0]), float(cgap[1])
+                sa, sb = (float(r) for r in utils.get_roots_of_EPP(params.R, params.temp, solution.A0, solution.A1))
+        itargmax = int(np.argmax(solution.E2))
+    finally:
+        # the record needs scalars only; an exception above must not leak the engine either (it goes back to the pool)
+        simulator.solver.close(fetch_U=False)
     return (solution.A0, solution.A1, ca, cb, sa, sb, solution.tau0, solution.t0, itargmax, run_id,
             np.nan if fac_A0 is None else fac_A0, np.nan if fac_A1 is None else fac_A1)
 

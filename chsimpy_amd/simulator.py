@@ -37,6 +37,10 @@ class Simulator:
         if on_update is None:
             # nothing an update could be shown on (simulator.py:33-34): one call for the whole run
             self.params.update_every = None
+        else:
+            # an observer between the chunks: every chunk is a solve_or_resume call of the reference to the letter,
+            # hat_U = dctn(U) recomputed on entry (solver.py:159) instead of carried on the device
+            self.solver.rederive_hat = True
 
     def solve(self):
         p = self.params

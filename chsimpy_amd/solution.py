@@ -7,6 +7,13 @@ from .timedata import TimeData
 _TIMEDATA_NAMES = ('E', 'E2', 'SA', 'domtime', 'Ra', 'L2', 'PS', 'delt', 'it_range')
 
 
+def _fingerprint(u):
+    """Two reductions over the field (~10 ms at N=4096, paid only after a download of 128 MB): enough to notice
+    any edit in place short of one constructed to preserve both."""
+    a = np.asarray(u)
+    return (a.shape, float(a.sum()), float(np.vdot(a, a)))
+
+
 class Solution:
     def __init__(self, params=None):
         p = self.params = params
@@ -50,8 +57,17 @@ class Solution:
         fetch = self.__dict__.get('_U_fetch')
         if fetch is not None:
             self.__dict__['_U_fetch'] = None
-            self.__dict__['_U'] = fetch()
+            u = self.__dict__['_U'] = fetch()
+            # the array handed out mirrors the device field: remember what it looked like, so that an edit in
+            # place (`sol.U[i, j] = x` in an update callback) is noticed by the next solve_or_resume, which the
+            # reference starts from this very array (solver.py:158)
+            self.__dict__['_U_print'] = _fingerprint(u)
         return self.__dict__.get('_U')
+
+    def _host_edited(self):
+        """True when the host mirror of the device field has been changed in place since it was downloaded."""
+        u, fp = self.__dict__.get('_U'), self.__dict__.get('_U_print')
+        return u is not None and fp is not None and _fingerprint(u) != fp
 
     @U.setter
     def U(self, value):
@@ -59,12 +75,14 @@ class Solution:
         # starts, so the next solve_or_resume uploads it
         self.__dict__['_U_fetch'] = None
         self.__dict__['_U'] = value
+        self.__dict__['_U_print'] = None
         self.__dict__['_U_dirty'] = value is not None
 
     def _bind_device_U(self, host_copy=None, fetch=None):
         """The engine's own field: `host_copy` mirrors it already, or `fetch()` downloads it on demand."""
         self.__dict__['_U'] = host_copy
         self.__dict__['_U_fetch'] = fetch
+        self.__dict__['_U_print'] = None
         self.__dict__['_U_dirty'] = False
 
     def __getstate__(self):

@@ -179,10 +179,12 @@ class Solver:
         if nsteps is None:
             nsteps = max(p.ntmax, 0)
         eng = self._engine
-        if self.solution.__dict__.get('_U_dirty'):
-            # the caller replaced the field since the last call: `U = self.solution.U` (solver.py:158)
-            eng.set_U(self.solution.U)
+        if self.solution.__dict__.get('_U_dirty') or self.solution._host_edited():
+            # the caller replaced the field since the last call -- by assignment, or by editing the array
+            # `solution.U` handed out in place: `U = self.solution.U` (solver.py:158) is where the reference starts
+            eng.set_U(self.solution.__dict__['_U'])
             self.solution.__dict__['_U_dirty'] = False
+            self.solution.__dict__['_U_print'] = None
         itbegin = 1 if self.solution.computed_steps == 1 else 0
         count = max(int(nsteps) - itbegin, 0)
 

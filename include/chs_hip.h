@@ -12,9 +12,11 @@
  * Conventions
  *   - plain pointers and sizes only; the caller owns every host buffer, the
  *     library owns the device buffers for the lifetime of the handle;
- *   - one opaque handle per simulation, one HIP stream per handle, no global
- *     state besides the thread-local last-error string -> 8 handles can live on
- *     8 devices of a node (ensemble runs, chsimpy/experiment.py:84-126);
+ *   - one opaque handle per simulation, one HIP stream and one pair of pinned staging
+ *     chunks per handle -> 8 handles can live on 8 devices of a node, and several on one
+ *     device move their fields concurrently (ensemble runs, chsimpy/experiment.py:84-126).
+ *     Library-owned state outside the handles: the thread-local last-error string and the
+ *     pool of parked engines (a mutex-protected free list, see chs_create / chs_pool_clear);
  *   - every call is synchronous on return;
  *   - return value: CHS_OK (0) or a negative CHS_E* code; chs_last_error()
  *     gives the text.
@@ -100,10 +102,15 @@ typedef struct chs_handle_s* chs_handle;
  * chs_destroy parks up to four engines (fields up to 160 MB) instead of freeing them and chs_create takes a
  * parked engine of the same device, N, dtype, transform engine and lambda table into use again with the new
  * constants -- an ensemble creates one engine per member; a run on such an engine is bit for bit the run on
- * a new one.  CHS_ENGINE_POOL=0 (read at both calls) switches that off.  A handle must not be used after
- * chs_destroy either way. */
+ * a new one.  The parked engines hold at most 3 GiB of device memory together (the least recently parked
+ * ones are freed first); chs_pool_clear() frees them all.  CHS_ENGINE_POOL=0 (read at both calls) switches
+ * the pool off.  A handle must not be used after chs_destroy either way.
+ * CHS_TEST_GATE_WITHHOLD=1 (test hook, read by chs_step_n): the in-launch bookkeeping of stop-rule / adaptive runs never publishes
+ * its decision, so that the waiting workgroups run into their bounded timeout -> chs_step_n returns CHS_EHIP. */
 int chs_create(const chs_consts* consts, const double* lambda, chs_handle* out);
 int chs_destroy(chs_handle h);
+/* Free every parked engine of this process (all devices). */
+int chs_pool_clear(void);
 
 /* Upload the N x N row-major float64 field (the reference's U_init / solution.U).
  * Replaces `U = self.U_init.copy()` (solver.py:85) and `U = self.solution.U`

@@ -51,3 +51,25 @@ def test_bench_as_ranks_of_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+
+
+def test_one_dead_rank_ends_the_launch_quickly(tmp_path):
+    """A rank that dies early (here: rank 1, before the rendezvous) must not leave its sibling waiting for the
+    collective's own timeout: the launcher notices the first non-zero exit, ends the others and fails, and it
+    shows every rank's stdout."""
+    import time
+    t0 = time.time()
+    r = _run(['--gpus', '2', '--steps', '5', '--dry-run'], CHS_DIST_BACKEND='gloo', CHS_BENCH_TEST_DIE_RANK='1')
+    assert r.returncode != 0
+    assert time.time() - t0 < 120
+    assert 'rank 1 exited with' in r.stderr
+
+
+def test_ensemble_baseline_cpu_leg_runs_the_protocol():
+    """`--ensemble-baseline` (CPU leg only under --dry-run): P oracle processes, 1 warm-up + 3 repetitions."""
+    r = _run(['--ensemble-baseline', '--dry-run', '--ens-procs', '2', '--ens-steps', '1'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    c = d['cpu_ensemble']
+    assert c['cores'] == 2 and c['kind'] == 'port' and c['value'] > 0 and c['best'] >= c['value']
+    assert '1 warm-up + 3 timed repetitions' in c['sample'] and 'gpu_ensemble' not in d

@@ -14,7 +14,7 @@ from oracle import chs_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-from gpu_helpers import GOLD, KAPPA, RTOL, compare_run, make, relerr  # noqa: F401
+from gpu_helpers import GOLD, KAPPA, RTOL, compare_run, log_line, make, relerr  # noqa: F401
 
 
 @pytest.mark.parametrize("engine,N", [('direct', 64), ('direct', 100), ('direct', 128), ('fast', 128), ('fast', 256),
@@ -489,6 +489,42 @@ def test_fp32_n8192_adaptive_runs(gpu):
     assert 0.8 < sol.U.min() and sol.U.max() < 0.95
     assert np.all(td[501:, 8] >= td[500, 8])                    # the step only grows here
     s.close()
+
+
+def test_fp32_n8192_adaptive_steps_vs_oracle_seeded_at_step_499(gpu):
+    """configs[3] against the ORACLE: the adaptive branch (solver.py:177-193) only fires beyond step 500, and 500
+    oracle steps at N=8192 would take an hour.  Both codes are therefore seeded at computed_steps = 499 from the
+    same start field -- the engine through chs_set_state, the oracle by its attribute -- and run 8 steps: records
+    499..506, delt re-evaluated at steps 502, 504 and 506 from the min column sum of the integrand over a
+    8192 x 8192 fp32 field (the fused row kernel's column partials, the two-stage reduction, lam1/lam2 regenerated
+    on the device, the gated tail).  fp32 against the fp64 oracle: delt 1e-4, E 1e-5, U 2e-4."""
+    N, steps, dmax = 8192, 8, 6e-11
+    kw = dict(adaptive_time=True, delt_max=dmax)
+    p = make(N, 10 ** 6, 'fast', dtype='float32', **kw)
+    s = chsimpy_amd.Solver(p)
+    s.prepare()
+    eng = s._engine
+    st = eng.get_state()
+    st.computed_steps = 499
+    eng.set_state(st)
+    rows, rc = eng.step_n(steps)
+    assert rc == 0 and rows.shape == (steps, 9)
+    U = eng.get_U()
+    o = orc.OracleSolver(orc.make_params(N, 10 ** 6, **kw))
+    o.prepare()
+    o.computed_steps = 499
+    o.solve_or_resume(steps)
+    to = o.timedata.data()[1:]
+    assert np.array_equal(rows[:, 0], to[:, 0]) and rows[0, 0] == 499 and rows[-1, 0] == 506
+    assert len(np.unique(to[:, 8])) == 4                       # delt: the seed value, then three re-evaluations
+    errs = {c: relerr(rows[:, c], to[:, c]) for c in (1, 2, 5, 6, 7, 8)}
+    log_line(f"N=8192 fp32 adaptive, seeded at step 499, 8 steps vs fp64 oracle: delt {errs[8]:.3e} E {errs[1]:.3e} "
+             f"E2 {errs[2]:.3e} Ra {errs[5]:.3e} L2 {errs[6]:.3e} PS {errs[7]:.3e} U {relerr(U, o.U):.3e}")
+    assert errs[8] < 1e-4, errs                                # the delt history (solver.py:183-188)
+    assert errs[1] < 1e-5 and errs[7] < 2e-3, errs             # E, PS
+    assert np.allclose(rows[:, 4], to[:, 4], rtol=1e-4)        # domtime = (sum delt / M_tilde)^(1/3)
+    assert np.allclose(U, o.U, rtol=2e-4, atol=0), relerr(U, o.U)
+    s.close(fetch_U=False)
 
 
 def test_adaptive_default_delt_max_blows_up_at_large_n_like_the_reference_quirk(gpu):

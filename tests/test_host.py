@@ -198,3 +198,23 @@ def test_simulator_chunk_sizes():
     assert list(chunk_sizes(7, 10)) == [7]            # dsteps = min(steps_end, update_every)
     assert list(chunk_sizes(0, 10)) == []
     assert list(itertools.islice(chunk_sizes(None, 100), 3)) == [100, 100, 100]   # time_max set: only the limit ends the run
+
+
+def test_in_place_edit_of_a_downloaded_field_is_noticed():
+    """`sol.U[i, j] = x` on the array the solution handed out (an update callback editing the field) must be seen
+    by the next solve_or_resume, which the reference starts from that very array (solver.py:158)."""
+    import chsimpy_amd
+    p = chsimpy_amd.Parameters()
+    p.N, p.kappa_tilde = 16, 0.0002989112919661156
+    sol = chsimpy_amd.Solution(p)
+    dev = np.full((16, 16), 0.875)
+    sol._bind_device_U(None, lambda: dev.copy())
+    assert not sol._host_edited()          # nothing downloaded yet: nothing to compare
+    u = sol.U
+    assert not sol._host_edited()
+    u[3, 4] = 0.87
+    assert sol._host_edited()
+    sol._bind_device_U(None, lambda: dev.copy())
+    assert not sol._host_edited()
+    sol.U = dev                            # assignment takes the other road (dirty flag)
+    assert sol.__dict__['_U_dirty'] and not sol._host_edited()
