@@ -7,7 +7,8 @@
 //  -> M = N/2 point complex FFT, decimation in frequency, 2 or 3 register-resident
 //     radix passes with the operands exchanged through a group-private LDS scratch
 //  -> real-FFT recombination of (Z[k], Z[M-k]) and the quarter-wave twiddle.
-// Each lane keeps E = M/G complex values in registers.  Two ownership tricks remove
+// Each lane keeps E = M/G complex values in registers, every one a Cx<T> (chs_cx.h: two fp64 registers, or one
+// packed fp32 register pair on which a complex add is ONE instruction).  Two ownership tricks remove
 // every exchange except the ones between radix passes:
 //   * pass 0 owns MIRROR PAIRS of butterflies (m', L1-1-m'): the 32-byte quads
 //     x[4q..4q+3] a lane loads contain exactly the operands of its two butterflies;
@@ -18,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include "chs_cx.h"
 
 // ---------------------------------------------------------------------------
 // compile-time configuration
@@ -26,6 +28,7 @@ template <typename T_, int N_, int G_, int THREADS_, int R0_, int RA_, int RB_, 
           int PADL_, int WPS_, int CT_ = THREADS_ / G_>
 struct FCfg {
   using T = T_;
+  using V = Cx<T_>;  // the complex value type of the core
   static constexpr int N = N_;
   static constexpr int M = N_ / 2;
   static constexpr int G = G_;          // lanes per transform (a "group")
@@ -82,133 +85,147 @@ struct FTables {
 };
 
 // ---------------------------------------------------------------------------
-// small complex helpers and the constant roots of unity (16th roots)
+// the constant roots of unity (16th roots) and the small DFTs
 // ---------------------------------------------------------------------------
 #define FC_SQRT1_2 0.70710678118654752440
 #define FC_COS_PI_8 0.92387953251128675613
 #define FC_SIN_PI_8 0.38268343236508977173
 
-// (r, i) *= exp(-2 pi i * IDX / 16)   (IDX taken mod 16); CONJ flips the sign of the angle
-template <typename T, int IDX, bool CONJ>
-__device__ __forceinline__ void mul_w16(T& r, T& i) {
-  constexpr int idx = ((CONJ ? -IDX : IDX) % 16 + 16) % 16;
+// index of exp(-2 pi i IDX/16) (CONJ flips the sign of the angle), reduced to 0..15
+template <int IDX, bool CONJ>
+struct W16 {
+  static constexpr int idx = ((CONJ ? -IDX : IDX) % 16 + 16) % 16;
+  static constexpr bool pure = (idx % 4) == 0;  // 1, -i, -1, +i: no multiplication
+};
+
+// a * exp(-2 pi i IDX/16)
+template <class V, int IDX, bool CONJ>
+__device__ __forceinline__ V mul_w16(V a) {
+  constexpr int idx = W16<IDX, CONJ>::idx;
+  using S = decltype(cx_re(a));
+  const V one = cx_make(S(1), S(1));
   if constexpr (idx == 0) {
-  } else if constexpr (idx == 4) {   // -i
-    T t = r; r = i; i = -t;
+    return a;
+  } else if constexpr (idx == 4) {   // -i: (i, -r)
+    return pk_mul_k<1, 0, 0, 1, 0, 1, 0, 0>(a, one);
   } else if constexpr (idx == 8) {
-    r = -r; i = -i;
-  } else if constexpr (idx == 12) {  // +i
-    T t = r; r = -i; i = t;
+    return pk_mul_k<0, 1, 0, 1, 1, 1, 0, 0>(a, one);
+  } else if constexpr (idx == 12) {  // +i: (-i, r)
+    return pk_mul_k<1, 0, 0, 1, 1, 0, 0, 0>(a, one);
   } else {
     // exp(-i a) = c - i s with a = 2 pi idx/16
     constexpr double cs[16] = {1.0, FC_COS_PI_8, FC_SQRT1_2, FC_SIN_PI_8, 0.0, -FC_SIN_PI_8, -FC_SQRT1_2, -FC_COS_PI_8,
                                -1.0, -FC_COS_PI_8, -FC_SQRT1_2, -FC_SIN_PI_8, 0.0, FC_SIN_PI_8, FC_SQRT1_2, FC_COS_PI_8};
     constexpr double sn[16] = {0.0, FC_SIN_PI_8, FC_SQRT1_2, FC_COS_PI_8, 1.0, FC_COS_PI_8, FC_SQRT1_2, FC_SIN_PI_8,
                                0.0, -FC_SIN_PI_8, -FC_SQRT1_2, -FC_COS_PI_8, -1.0, -FC_COS_PI_8, -FC_SQRT1_2, -FC_SIN_PI_8};
-    const T c = (T)cs[idx], s = (T)sn[idx];
-    const T nr = r * c + i * s;
-    const T ni = i * c - r * s;
-    r = nr; i = ni;
+    return cx_mul_k(a, cx_make((S)cs[idx], (S)-sn[idx]));
   }
 }
 
-// In-place DFT of size R on re[0..R), im[0..R): y[k] = sum_j a[j] exp(-+2 pi i jk/R)
+// (a, b) <- (a + w b, a - w b) for a pure 16th root w = exp(-2 pi i ROT/16) in {1, -i, -1, +i}: the rotation
+// is folded into the two additions
+template <class V, int ROT>
+__device__ __forceinline__ void bfly2_rot(V& a, V& b) {
+  static_assert(ROT % 4 == 0, "pure rotations only");
+  constexpr int r = ((ROT % 16) + 16) % 16;
+  const V x = a, y = b;
+  if constexpr (r == 0) { a = cx_add(x, y); b = cx_sub(x, y); }
+  else if constexpr (r == 4) { a = cx_add_mi(x, y); b = cx_add_pi(x, y); }
+  else if constexpr (r == 8) { a = cx_sub(x, y); b = cx_add(x, y); }
+  else { a = cx_add_pi(x, y); b = cx_add_mi(x, y); }
+}
+
+// In-place DFT of size R on z[0..R): y[k] = sum_j a[j] exp(-+2 pi i jk/R)
 // (INV: conjugate roots, unnormalised).  Natural order in and out.
-template <typename T, int R, bool INV>
+template <class V, int R, bool INV>
 struct Dft;
 
-template <typename T, bool INV>
-struct Dft<T, 1, INV> {
-  static __device__ __forceinline__ void run(T*, T*) {}
+template <class V, bool INV>
+struct Dft<V, 1, INV> {
+  static __device__ __forceinline__ void run(V*) {}
 };
 
-template <typename T, bool INV>
-struct Dft<T, 2, INV> {
-  static __device__ __forceinline__ void run(T* re, T* im) {
-    const T r = re[0] - re[1], i = im[0] - im[1];
-    re[0] += re[1]; im[0] += im[1];
-    re[1] = r; im[1] = i;
-  }
+template <class V, bool INV>
+struct Dft<V, 2, INV> {
+  static __device__ __forceinline__ void run(V* z) { bfly2_rot<V, 0>(z[0], z[1]); }
 };
 
-template <typename T, bool INV>
-struct Dft<T, 4, INV> {
-  static __device__ __forceinline__ void run(T* re, T* im) {
-    const T t0r = re[0] + re[2], t0i = im[0] + im[2];
-    const T t1r = re[0] - re[2], t1i = im[0] - im[2];
-    const T t2r = re[1] + re[3], t2i = im[1] + im[3];
-    T t3r = re[1] - re[3], t3i = im[1] - im[3];
-    mul_w16<T, 4, INV>(t3r, t3i);  // * (-i) forward, * (+i) inverse
-    re[0] = t0r + t2r; im[0] = t0i + t2i;
-    re[2] = t0r - t2r; im[2] = t0i - t2i;
-    re[1] = t1r + t3r; im[1] = t1i + t3i;
-    re[3] = t1r - t3r; im[3] = t1i - t3i;
+template <class V, bool INV>
+struct Dft<V, 4, INV> {
+  static __device__ __forceinline__ void run(V* z) {
+    const V t0 = cx_add(z[0], z[2]), t1 = cx_sub(z[0], z[2]);
+    const V t2 = cx_add(z[1], z[3]), t3 = cx_sub(z[1], z[3]);
+    z[0] = cx_add(t0, t2);
+    z[2] = cx_sub(t0, t2);
+    // t1 +- (-i) t3 forward, t1 +- (+i) t3 inverse
+    if constexpr (!INV) { z[1] = cx_add_mi(t1, t3); z[3] = cx_add_pi(t1, t3); }
+    else { z[1] = cx_add_pi(t1, t3); z[3] = cx_add_mi(t1, t3); }
   }
 };
 
 // R = A*B Cooley-Tukey with A = 4:  n = B n1 + n2,  k = k1 + A k2
-template <typename T, int R, bool INV>
+template <class V, int R, bool INV>
 struct Dft {
   static constexpr int A = 4, B = R / 4;
   static_assert(R == 8 || R == 16, "radix must be 2, 4, 8 or 16");
   template <int N2, int K1>
-  static __device__ __forceinline__ void tw(T& r, T& i) {
-    mul_w16<T, (N2 * K1 * 16) / R, INV>(r, i);
+  static constexpr int tw_idx() { return (N2 * K1 * 16) / R; }
+  // the twiddle between the two stages; B == 2: a pure rotation is left to the second stage (bfly2_rot)
+  template <int N2, int K1>
+  static __device__ __forceinline__ V tw(V a) {
+    if constexpr (B == 2 && W16<tw_idx<N2, K1>(), INV>::pure) return a;
+    else return mul_w16<V, tw_idx<N2, K1>(), INV>(a);
   }
   template <int N2>
-  static __device__ __forceinline__ void col(const T* re, const T* im, T (*cr)[A], T (*ci)[A]) {
-    T xr[A], xi[A];
+  static __device__ __forceinline__ void col(const V* z, V (*c)[A]) {
+    V x[A];
 #pragma unroll
-    for (int n1 = 0; n1 < A; ++n1) { xr[n1] = re[B * n1 + N2]; xi[n1] = im[B * n1 + N2]; }
-    Dft<T, A, INV>::run(xr, xi);
-    tw<N2, 1>(xr[1], xi[1]);
-    tw<N2, 2>(xr[2], xi[2]);
-    tw<N2, 3>(xr[3], xi[3]);
-#pragma unroll
-    for (int k1 = 0; k1 < A; ++k1) { cr[N2][k1] = xr[k1]; ci[N2][k1] = xi[k1]; }
+    for (int n1 = 0; n1 < A; ++n1) x[n1] = z[B * n1 + N2];
+    Dft<V, A, INV>::run(x);
+    c[N2][0] = x[0];
+    c[N2][1] = tw<N2, 1>(x[1]);
+    c[N2][2] = tw<N2, 2>(x[2]);
+    c[N2][3] = tw<N2, 3>(x[3]);
   }
-  static __device__ __forceinline__ void run(T* re, T* im) {
-    T cr[B][A], ci[B][A];
-    col<0>(re, im, cr, ci);
-    col<1>(re, im, cr, ci);
+  template <int K1>
+  static __device__ __forceinline__ void row(V* z, V (*c)[A]) {
+    if constexpr (B == 2) {
+      V y0 = c[0][K1], y1 = c[1][K1];
+      constexpr int rot = W16<tw_idx<1, K1>(), INV>::pure ? W16<tw_idx<1, K1>(), INV>::idx : 0;
+      bfly2_rot<V, rot>(y0, y1);
+      z[K1] = y0; z[K1 + A] = y1;
+    } else {
+      V y[B];
+#pragma unroll
+      for (int n2 = 0; n2 < B; ++n2) y[n2] = c[n2][K1];
+      Dft<V, B, INV>::run(y);
+#pragma unroll
+      for (int k2 = 0; k2 < B; ++k2) z[K1 + A * k2] = y[k2];
+    }
+  }
+  static __device__ __forceinline__ void run(V* z) {
+    V c[B][A];
+    col<0>(z, c);
+    col<1>(z, c);
     if constexpr (B == 4) {
-      col<2>(re, im, cr, ci);
-      col<3>(re, im, cr, ci);
+      col<2>(z, c);
+      col<3>(z, c);
     }
-#pragma unroll
-    for (int k1 = 0; k1 < A; ++k1) {
-      T yr[B], yi[B];
-#pragma unroll
-      for (int n2 = 0; n2 < B; ++n2) { yr[n2] = cr[n2][k1]; yi[n2] = ci[n2][k1]; }
-      Dft<T, B, INV>::run(yr, yi);
-#pragma unroll
-      for (int k2 = 0; k2 < B; ++k2) { re[k1 + A * k2] = yr[k2]; im[k1 + A * k2] = yi[k2]; }
-    }
+    row<0>(z, c);
+    row<1>(z, c);
+    row<2>(z, c);
+    row<3>(z, c);
   }
 };
 
-// (r, i) *= (wr, wi)  or  *= conj(wr, wi)
-template <typename T, bool CONJ>
-__device__ __forceinline__ void cmul(T& r, T& i, T wr, T wi) {
-  if constexpr (!CONJ) {
-    const T nr = r * wr - i * wi;
-    const T ni = r * wi + i * wr;
-    r = nr; i = ni;
-  } else {
-    const T nr = r * wr + i * wi;
-    const T ni = i * wr - r * wi;
-    r = nr; i = ni;
-  }
-}
-
+// twiddle tables hold complex values interleaved (re, im): one 16-byte (fp64) or 8-byte (fp32) load
 template <typename T>
-__device__ __forceinline__ void ldc(const T* __restrict__ tab, int idx, T& r, T& i) {
+__device__ __forceinline__ Cx<T> ldc(const T* __restrict__ tab, int idx) {
   if constexpr (sizeof(T) == 8) {
     const double2 v = *reinterpret_cast<const double2*>(tab + 2 * (size_t)idx);
-    r = v.x; i = v.y;
+    return cx_make(v.x, v.y);
   } else {
-    const float2 v = *reinterpret_cast<const float2*>(tab + 2 * (size_t)idx);
-    r = v.x; i = v.y;
+    return *reinterpret_cast<const v2f*>(tab + 2 * (size_t)idx);
   }
 }
 
@@ -261,115 +278,93 @@ struct Own {
 // the three recombination twiddles of one slot
 template <typename T>
 struct SlotTw {
-  T wr, wi, ar, ai, br, bi;
+  Cx<T> w, a, b;
 };
 template <typename T>
 __device__ __forceinline__ SlotTw<T> slot_tw(const FTables<T>& tb, int kk) {
   SlotTw<T> w;
-  ldc(tb.wp, kk, w.wr, w.wi);
-  ldc(tb.t1, kk, w.ar, w.ai);
-  ldc(tb.t2, kk, w.br, w.bi);
+  w.w = ldc<T>(tb.wp, kk);
+  w.a = ldc<T>(tb.t1, kk);
+  w.b = ldc<T>(tb.t2, kk);
   return w;
 }
 
+// (A, Z) -> Ya = (y0, y1), Yb = (y2, y3): the four real coefficients of the slot
 template <typename T>
-__device__ __forceinline__ void slot_fwd(T Ar, T Ai, T Zr, T Zi, const SlotTw<T>& w, T& y0, T& y1, T& y2, T& y3) {
+__device__ __forceinline__ void slot_fwd(Cx<T> A, Cx<T> Z, const SlotTw<T>& w, Cx<T>& Ya, Cx<T>& Yb) {
   // B = conj(Z2); P = A + B; D = A - B
-  const T Pr = Ar + Zr, Pi = Ai - Zi;
-  T Dr = Ar - Zr, Di = Ai + Zi;
-  const T wr = w.wr, wi = w.wi, ar = w.ar, ai = w.ai, br = w.br, bi = w.bi;
-  cmul<T, false>(Dr, Di, wr, wi);  // Q = w' D
-  const T S1r = Pr + Dr, S1i = Pi + Di;
-  const T S2r = Pr - Dr, S2i = Pi - Di;
-  y0 = ar * S1r - ai * S1i;      // Re(T1 S1)
-  y1 = -(ar * S1i + ai * S1r);   // -Im(T1 S1)
-  y2 = br * S2r - bi * S2i;      // Re(T2 S2)
-  y3 = br * S2i + bi * S2r;      // Im(T2 S2)
+  const Cx<T> P = cx_addc(A, Z), D = cx_subc(A, Z);
+  const Cx<T> Q = cx_mul(D, w.w);            // Q = w' D
+  const Cx<T> S1 = cx_add(P, Q), S2 = cx_sub(P, Q);
+  Ya = cx_mul_cj(S1, w.a);                   // (Re(T1 S1), -Im(T1 S1))
+  Yb = cx_mul(S2, w.b);                      // (Re(T2 S2),  Im(T2 S2))
 }
 
 template <typename T>
-__device__ __forceinline__ void slot_adj(T y0, T y1, T y2, T y3, const SlotTw<T>& w, T& gAr, T& gAi, T& gZr, T& gZi) {
-  const T wr = w.wr, wi = w.wi, ar = w.ar, ai = w.ai, br = w.br, bi = w.bi;
+__device__ __forceinline__ void slot_adj(Cx<T> Ya, Cx<T> Yb, const SlotTw<T>& w, Cx<T>& gA, Cx<T>& gZ) {
   // gS1 = conj(T1 * (y0 + i y1));  gS2 = conj(T2) * (y2 + i y3)
-  const T g1r = ar * y0 - ai * y1, g1i = -(ar * y1 + ai * y0);
-  const T g2r = br * y2 + bi * y3, g2i = br * y3 - bi * y2;
-  const T gPr = g1r + g2r, gPi = g1i + g2i;
-  T gDr = g1r - g2r, gDi = g1i - g2i;
-  cmul<T, true>(gDr, gDi, wr, wi);  // gD = conj(w') gQ
-  gAr = gPr + gDr; gAi = gPi + gDi;
-  // gB = gP - gD ; gZ2 = conj(gB)
-  gZr = gPr - gDr; gZi = -(gPi - gDi);
+  const Cx<T> g1 = cx_mul_cj(Ya, w.a), g2 = cx_mulc(Yb, w.b);
+  const Cx<T> gP = cx_add(g1, g2);
+  const Cx<T> gD = cx_mulc(cx_sub(g1, g2), w.w);  // gD = conj(w') gQ
+  gA = cx_add(gP, gD);
+  gZ = cx_sub_cj(gP, gD);                    // gB = gP - gD ; gZ2 = conj(gB)
 }
-
-// ---------------------------------------------------------------------------
-// LDS exchange helpers.  `scr` points at the group's scratch (C::SCR elements);
-// fp64: real and imaginary parts travel one after the other through the same scratch,
-// fp32 (C::PAIR): together, as one 8-byte item per value.
-// ---------------------------------------------------------------------------
 
 // ===========================================================================
-// Radix passes.  Register index conventions:
+// Radix passes.  Register index conventions (z[] = the lane's E complex values):
 //   pass 0 operands / results   ((q*2+b)*R0 + j)   q < NP0 mirror pairs, b: m1 | m2 = L1-1-m1
 //   pass A / pass B             (ib*R + j)          butterfly id = l + G*ib -> (kappa = id % S, m = id / S)
 //   last pass                   ((q*2+b)*RL + j)    q < NP2 mirror pairs, b: kappa1 | kappa2
-// Exchange buffers (real and imaginary parts travel one after the other through `scr`):
+// Exchange buffers in the group's LDS scratch `scr` (C::SCR elements):
 //   X1[kappa][m] at kappa*P1 + m,  X2[kappa][m] at kappa*P2 + m,  XL[m][kappa] at m*PL + kappa.
+// fp32 (C::PAIR): a value travels as one 8-byte item (the register pair as it stands); fp64: the real parts of
+// all values first, then the imaginary parts through the same scratch (half the LDS).
 // ===========================================================================
 
 // one middle pass of the forward transform, in registers
 template <class C, int S_IN, int L_OUT, int R, int NB>
-__device__ __forceinline__ void mid_fwd(typename C::T* re, typename C::T* im, const typename C::T* tw, int l) {
+__device__ __forceinline__ void mid_fwd(typename C::V* z, const typename C::T* tw, int l) {
   using T = typename C::T;
+  using V = typename C::V;
 #pragma unroll
   for (int ib = 0; ib < NB; ++ib) {
     const int mm = (l + C::G * ib) / S_IN;
-    T* r = re + ib * R;
-    T* i = im + ib * R;
-    Dft<T, R, false>::run(r, i);
+    V* r = z + ib * R;
+    Dft<V, R, false>::run(r);
 #pragma unroll
-    for (int k = 1; k < R; ++k) {
-      T wr, wi;
-      ldc(tw, (k - 1) * L_OUT + mm, wr, wi);
-      cmul<T, false>(r[k], i[k], wr, wi);
-    }
+    for (int k = 1; k < R; ++k) r[k] = cx_mul(r[k], ldc<T>(tw, (k - 1) * L_OUT + mm));
   }
 }
 template <class C, int S_IN, int L_OUT, int R, int NB>
-__device__ __forceinline__ void mid_inv(typename C::T* re, typename C::T* im, const typename C::T* tw, int l) {
+__device__ __forceinline__ void mid_inv(typename C::V* z, const typename C::T* tw, int l) {
   using T = typename C::T;
+  using V = typename C::V;
 #pragma unroll
   for (int ib = 0; ib < NB; ++ib) {
     const int mm = (l + C::G * ib) / S_IN;
-    T* r = re + ib * R;
-    T* i = im + ib * R;
+    V* r = z + ib * R;
 #pragma unroll
-    for (int k = 1; k < R; ++k) {
-      T wr, wi;
-      ldc(tw, (k - 1) * L_OUT + mm, wr, wi);
-      cmul<T, true>(r[k], i[k], wr, wi);
-    }
-    Dft<T, R, true>::run(r, i);
+    for (int k = 1; k < R; ++k) r[k] = cx_mulc(r[k], ldc<T>(tw, (k - 1) * L_OUT + mm));
+    Dft<V, R, true>::run(r);
   }
 }
 
-// ---- register <-> LDS movers; WR = true: registers -> LDS, false: LDS -> registers
-template <class C, bool WR>
-__device__ __forceinline__ void xfer(typename C::T& reg, typename C::T& reg2, typename C::T* scr, int addr) {
+// ---- register <-> LDS movers; WR = true: registers -> LDS, false: LDS -> registers; PART (fp64 only): 0 = the
+// real parts, 1 = the imaginary parts
+template <class C, bool WR, int PART>
+__device__ __forceinline__ void xfer(typename C::V& v, typename C::T* scr, int addr) {
   if constexpr (C::PAIR) {
-    float2* s2 = reinterpret_cast<float2*>(scr);
-    if constexpr (WR) {
-      s2[addr] = make_float2(reg, reg2);
-    } else {
-      const float2 t = s2[addr];
-      reg = t.x; reg2 = t.y;
-    }
+    v2f* s2 = reinterpret_cast<v2f*>(scr);
+    if constexpr (WR) s2[addr] = v; else v = s2[addr];
   } else {
-    if constexpr (WR) scr[addr] = reg; else reg = scr[addr];
+    if constexpr (WR) scr[addr] = PART ? v.y : v.x;
+    else if constexpr (PART) v.y = scr[addr];
+    else v.x = scr[addr];
   }
 }
 // pass-0 results (q,b,k) <-> X1[k][m_b]   (or XL[m_b][k] when there is no middle pass)
-template <class C, bool WR>
-__device__ __forceinline__ void mv_pass0(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
+template <class C, bool WR, int PART>
+__device__ __forceinline__ void mv_pass0(typename C::V* z, typename C::T* scr, int l) {
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
     const int m1 = l + C::G * q;
@@ -378,90 +373,88 @@ __device__ __forceinline__ void mv_pass0(typename C::T* v, typename C::T* w, typ
       const int m = b ? (C::L1 - 1 - m1) : m1;
 #pragma unroll
       for (int k = 0; k < C::R0; ++k) {
-        if constexpr (C::RA > 1) xfer<C, WR>(v[(q * 2 + b) * C::R0 + k], w[(q * 2 + b) * C::R0 + k], scr, k * C::P1 + m);
-        else xfer<C, WR>(v[(q * 2 + b) * C::R0 + k], w[(q * 2 + b) * C::R0 + k], scr, m * C::PL + k);
+        if constexpr (C::RA > 1) xfer<C, WR, PART>(z[(q * 2 + b) * C::R0 + k], scr, k * C::P1 + m);
+        else xfer<C, WR, PART>(z[(q * 2 + b) * C::R0 + k], scr, m * C::PL + k);
       }
     }
   }
 }
 // pass-A operands (ib,j) <-> X1[kappa][mm + L2*j]
-template <class C, bool WR>
-__device__ __forceinline__ void mv_a_in(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
+template <class C, bool WR, int PART>
+__device__ __forceinline__ void mv_a_in(typename C::V* z, typename C::T* scr, int l) {
 #pragma unroll
   for (int ib = 0; ib < C::NBA; ++ib) {
     const int id = l + C::G * ib;
     const int kap = id % C::S1, mm = id / C::S1;
 #pragma unroll
-    for (int j = 0; j < C::RA; ++j) xfer<C, WR>(v[ib * C::RA + j], w[ib * C::RA + j], scr, kap * C::P1 + mm + C::L2 * j);
+    for (int j = 0; j < C::RA; ++j) xfer<C, WR, PART>(z[ib * C::RA + j], scr, kap * C::P1 + mm + C::L2 * j);
   }
 }
 // pass-A results (ib,k) <-> X2[kappa + S1*k][mm]   (or XL[mm][kappa + S1*k] when pass B is absent)
-template <class C, bool WR>
-__device__ __forceinline__ void mv_a_out(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
+template <class C, bool WR, int PART>
+__device__ __forceinline__ void mv_a_out(typename C::V* z, typename C::T* scr, int l) {
 #pragma unroll
   for (int ib = 0; ib < C::NBA; ++ib) {
     const int id = l + C::G * ib;
     const int kap = id % C::S1, mm = id / C::S1;
 #pragma unroll
     for (int k = 0; k < C::RA; ++k) {
-      if constexpr (C::RB > 1) xfer<C, WR>(v[ib * C::RA + k], w[ib * C::RA + k], scr, (kap + C::S1 * k) * C::P2 + mm);
-      else xfer<C, WR>(v[ib * C::RA + k], w[ib * C::RA + k], scr, mm * C::PL + kap + C::S1 * k);
+      if constexpr (C::RB > 1) xfer<C, WR, PART>(z[ib * C::RA + k], scr, (kap + C::S1 * k) * C::P2 + mm);
+      else xfer<C, WR, PART>(z[ib * C::RA + k], scr, mm * C::PL + kap + C::S1 * k);
     }
   }
 }
 // pass-B operands (ib,j) <-> X2[kappa][mm + L3*j]
-template <class C, bool WR>
-__device__ __forceinline__ void mv_b_in(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
+template <class C, bool WR, int PART>
+__device__ __forceinline__ void mv_b_in(typename C::V* z, typename C::T* scr, int l) {
 #pragma unroll
   for (int ib = 0; ib < C::NBB; ++ib) {
     const int id = l + C::G * ib;
     const int kap = id % C::S2A, mm = id / C::S2A;
 #pragma unroll
-    for (int j = 0; j < C::RB; ++j) xfer<C, WR>(v[ib * C::RB + j], w[ib * C::RB + j], scr, kap * C::P2 + mm + C::L3 * j);
+    for (int j = 0; j < C::RB; ++j) xfer<C, WR, PART>(z[ib * C::RB + j], scr, kap * C::P2 + mm + C::L3 * j);
   }
 }
 // pass-B results (ib,k) <-> XL[mm][kappa + S2A*k]
-template <class C, bool WR>
-__device__ __forceinline__ void mv_b_out(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
+template <class C, bool WR, int PART>
+__device__ __forceinline__ void mv_b_out(typename C::V* z, typename C::T* scr, int l) {
 #pragma unroll
   for (int ib = 0; ib < C::NBB; ++ib) {
     const int id = l + C::G * ib;
     const int kap = id % C::S2A, mm = id / C::S2A;
 #pragma unroll
-    for (int k = 0; k < C::RB; ++k) xfer<C, WR>(v[ib * C::RB + k], w[ib * C::RB + k], scr, mm * C::PL + kap + C::S2A * k);
+    for (int k = 0; k < C::RB; ++k) xfer<C, WR, PART>(z[ib * C::RB + k], scr, mm * C::PL + kap + C::S2A * k);
   }
 }
 // last-pass operands (q,b,j) <-> XL[j][kappa_b]
-template <class C, bool WR>
-__device__ __forceinline__ void mv_last(typename C::T* v, typename C::T* w, typename C::T* scr, int l) {
+template <class C, bool WR, int PART>
+__device__ __forceinline__ void mv_last(typename C::V* z, typename C::T* scr, int l) {
 #pragma unroll
   for (int q = 0; q < C::NP2; ++q) {
     int k1, k2; bool sp;
     Own<C>::last_pair(l, q, k1, k2, sp);
 #pragma unroll
     for (int j = 0; j < C::RL; ++j) {
-      xfer<C, WR>(v[(q * 2 + 0) * C::RL + j], w[(q * 2 + 0) * C::RL + j], scr, j * C::PL + k1);
-      xfer<C, WR>(v[(q * 2 + 1) * C::RL + j], w[(q * 2 + 1) * C::RL + j], scr, j * C::PL + k2);
+      xfer<C, WR, PART>(z[(q * 2 + 0) * C::RL + j], scr, j * C::PL + k1);
+      xfer<C, WR, PART>(z[(q * 2 + 1) * C::RL + j], scr, j * C::PL + k2);
     }
   }
 }
 
 // one exchange: WRITER moves the registers out, READER brings the new ownership in
-#define CHS_EXCHANGE(WRITER, READER)              \
-  do {                                            \
-    if constexpr (C::PAIR) {                      \
-      xsync<C>(); WRITER(re, im, scr, l); xsync<C>(); READER(re, im, scr, l); \
-    } else {                                      \
-      xsync<C>(); WRITER(re, re, scr, l); xsync<C>(); READER(re, re, scr, l); \
-      xsync<C>(); WRITER(im, im, scr, l); xsync<C>(); READER(im, im, scr, l); \
-    }                                             \
+#define CHS_EXCHANGE(WRITER, READER)                                                   \
+  do {                                                                                 \
+    xsync<C>(); WRITER<C, true, 0>(z, scr, l); xsync<C>(); READER<C, false, 0>(z, scr, l);   \
+    if constexpr (!C::PAIR) {                                                          \
+      xsync<C>(); WRITER<C, true, 1>(z, scr, l); xsync<C>(); READER<C, false, 1>(z, scr, l); \
+    }                                                                                  \
   } while (0)
 
 // Forward: pass-0 operands in -> last-pass outputs Z out (index ((q*2+b)*RL + k)).
 template <class C>
-__device__ __forceinline__ void fwd_passes(typename C::T* re, typename C::T* im, typename C::T* scr,
-                                           const FTables<typename C::T>& tb, int l) {
+__device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr, const FTables<typename C::T>& tb, int l) {
   using T = typename C::T;
+  using V = typename C::V;
   // ---- pass 0: radix R0 on every owned butterfly, then twiddle by omega_M^(m k)
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
@@ -469,54 +462,49 @@ __device__ __forceinline__ void fwd_passes(typename C::T* re, typename C::T* im,
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int m = b ? (C::L1 - 1 - m1) : m1;
-      T* r = re + (q * 2 + b) * C::R0;
-      T* i = im + (q * 2 + b) * C::R0;
-      Dft<T, C::R0, false>::run(r, i);
+      V* r = z + (q * 2 + b) * C::R0;
+      Dft<V, C::R0, false>::run(r);
 #pragma unroll
-      for (int k = 1; k < C::R0; ++k) {
-        T wr, wi;
-        ldc(tb.tw0, (k - 1) * C::L1 + m, wr, wi);
-        cmul<T, false>(r[k], i[k], wr, wi);
-      }
+      for (int k = 1; k < C::R0; ++k) r[k] = cx_mul(r[k], ldc<T>(tb.tw0, (k - 1) * C::L1 + m));
     }
   }
   if constexpr (C::RA > 1) {
-    CHS_EXCHANGE((mv_pass0<C, true>), (mv_a_in<C, false>));
-    mid_fwd<C, C::S1, C::L2, C::RA, C::NBA>(re, im, tb.twa, l);
+    CHS_EXCHANGE(mv_pass0, mv_a_in);
+    mid_fwd<C, C::S1, C::L2, C::RA, C::NBA>(z, tb.twa, l);
     if constexpr (C::RB > 1) {
-      CHS_EXCHANGE((mv_a_out<C, true>), (mv_b_in<C, false>));
-      mid_fwd<C, C::S2A, C::L3, C::RB, C::NBB>(re, im, tb.twb, l);
-      CHS_EXCHANGE((mv_b_out<C, true>), (mv_last<C, false>));
+      CHS_EXCHANGE(mv_a_out, mv_b_in);
+      mid_fwd<C, C::S2A, C::L3, C::RB, C::NBB>(z, tb.twb, l);
+      CHS_EXCHANGE(mv_b_out, mv_last);
     } else {
-      CHS_EXCHANGE((mv_a_out<C, true>), (mv_last<C, false>));
+      CHS_EXCHANGE(mv_a_out, mv_last);
     }
   } else {
-    CHS_EXCHANGE((mv_pass0<C, true>), (mv_last<C, false>));
+    CHS_EXCHANGE(mv_pass0, mv_last);
   }
   // ---- last pass
 #pragma unroll
-  for (int q = 0; q < 2 * C::NP2; ++q) Dft<T, C::RL, false>::run(re + q * C::RL, im + q * C::RL);
+  for (int q = 0; q < 2 * C::NP2; ++q) Dft<V, C::RL, false>::run(z + q * C::RL);
 }
 
 // Inverse (exact transpose): last-pass output gradients in -> pass-0 operands out.
 template <class C>
-__device__ __forceinline__ void inv_passes(typename C::T* re, typename C::T* im, typename C::T* scr,
-                                           const FTables<typename C::T>& tb, int l) {
+__device__ __forceinline__ void inv_passes(typename C::V* z, typename C::T* scr, const FTables<typename C::T>& tb, int l) {
   using T = typename C::T;
+  using V = typename C::V;
 #pragma unroll
-  for (int q = 0; q < 2 * C::NP2; ++q) Dft<T, C::RL, true>::run(re + q * C::RL, im + q * C::RL);
+  for (int q = 0; q < 2 * C::NP2; ++q) Dft<V, C::RL, true>::run(z + q * C::RL);
   if constexpr (C::RA > 1) {
     if constexpr (C::RB > 1) {
-      CHS_EXCHANGE((mv_last<C, true>), (mv_b_out<C, false>));
-      mid_inv<C, C::S2A, C::L3, C::RB, C::NBB>(re, im, tb.twb, l);
-      CHS_EXCHANGE((mv_b_in<C, true>), (mv_a_out<C, false>));
+      CHS_EXCHANGE(mv_last, mv_b_out);
+      mid_inv<C, C::S2A, C::L3, C::RB, C::NBB>(z, tb.twb, l);
+      CHS_EXCHANGE(mv_b_in, mv_a_out);
     } else {
-      CHS_EXCHANGE((mv_last<C, true>), (mv_a_out<C, false>));
+      CHS_EXCHANGE(mv_last, mv_a_out);
     }
-    mid_inv<C, C::S1, C::L2, C::RA, C::NBA>(re, im, tb.twa, l);
-    CHS_EXCHANGE((mv_a_in<C, true>), (mv_pass0<C, false>));
+    mid_inv<C, C::S1, C::L2, C::RA, C::NBA>(z, tb.twa, l);
+    CHS_EXCHANGE(mv_a_in, mv_pass0);
   } else {
-    CHS_EXCHANGE((mv_last<C, true>), (mv_pass0<C, false>));
+    CHS_EXCHANGE(mv_last, mv_pass0);
   }
   // ---- pass 0 transposed
 #pragma unroll
@@ -525,15 +513,10 @@ __device__ __forceinline__ void inv_passes(typename C::T* re, typename C::T* im,
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int m = b ? (C::L1 - 1 - m1) : m1;
-      T* r = re + (q * 2 + b) * C::R0;
-      T* i = im + (q * 2 + b) * C::R0;
+      V* r = z + (q * 2 + b) * C::R0;
 #pragma unroll
-      for (int k = 1; k < C::R0; ++k) {
-        T wr, wi;
-        ldc(tb.tw0, (k - 1) * C::L1 + m, wr, wi);
-        cmul<T, true>(r[k], i[k], wr, wi);
-      }
-      Dft<T, C::R0, true>::run(r, i);
+      for (int k = 1; k < C::R0; ++k) r[k] = cx_mulc(r[k], ldc<T>(tb.tw0, (k - 1) * C::L1 + m));
+      Dft<V, C::R0, true>::run(r);
     }
   }
 }
@@ -568,22 +551,22 @@ __device__ __forceinline__ int fc_opaque(int x) {
   return x;
 }
 
-// Recombination slots of one lane.  PIPE = 1: the twiddles of slot k+1 and whatever `pre(pbase, idx)`
-// fetches for it (global loads only) are requested after slot k's `f(pbase, idx, y, live, fetched)`
-// has computed its results and before `st(pbase, idx, y, live)` stores them; PIPE = 2: already at the
-// start of slot k (a whole slot of latency cover for more live registers).  A load requested after
-// a store cannot be waited for without waiting for the store too (one in-order vmcnt counter), so
-// without this every slot would sit out the full latency of the previous slot's stores.
-// PIPE = 0: everything of slot k is fetched in slot k (f may load and store as it likes, st is empty).
-template <class C, bool FWD, bool ADJ, int PIPE, class PRE, class F, class ST>
-__device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, const FTables<typename C::T>& tb,
-                                          int l, PRE&& pre, F&& f, ST&& st) {
+// Recombination slots of one lane.  PIPE: the twiddles of slot k+1 and whatever `pre(pbase, idx)` fetches for it
+// (global loads only) are requested after slot k's `f(pbase, idx, y, live, fetched)` has computed its results
+// and before `st(pbase, idx, y, live)` stores them.  A load requested after a store cannot be waited for without
+// waiting for the store too (one in-order vmcnt counter), so without this every slot would sit out the full
+// latency of the previous slot's stores.  !PIPE: everything of slot k is fetched in slot k (f may load and store
+// as it likes, st is empty).
+template <class C, bool FWD, bool ADJ, bool PIPE, class PRE, class F, class ST>
+__device__ __forceinline__ void recombine(typename C::V* z, const FTables<typename C::T>& tb, int l, PRE&& pre, F&& f, ST&& st) {
   using T = typename C::T;
+  using V = typename C::V;
   constexpr int R2 = C::R2, N = C::N, M = C::M, H = R2 / 2;
+  const V zero = cx_make(T(0), T(0));
 #pragma unroll
   for (int q = 0; q < C::NP2; ++q) {
-    T* r1 = re + (q * 2 + 0) * R2; T* i1 = im + (q * 2 + 0) * R2;
-    T* r2 = re + (q * 2 + 1) * R2; T* i2 = im + (q * 2 + 1) * R2;
+    V* r1 = z + (q * 2 + 0) * R2;
+    V* r2 = z + (q * 2 + 1) * R2;
     const int kap = l + C::G * q;
     // Only butterfly pair 0 = (0, S2/2) (lane 0, q = 0) pairs its outputs inside its own butterflies.
     // A wavefront without that lane runs the plain slots; the wavefront holding it runs the same
@@ -612,20 +595,19 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
         }
         const SlotTw<T> w = wn;  // shared by the forward and the adjoint half
         const auto pc = pn;
-        auto fetch_next = [&]() {
+        V Ya = zero, Yb = zero;
+        if constexpr (FWD) slot_fwd<T>(r1[k], r2[R2 - 1 - k], w, Ya, Yb);
+        T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
+        const int idx[4] = {kk, N - kk, M - kk, M + kk};
+        f((q * R2 + k) * 4, idx, y, true, pc);
+        if (PIPE && k + 1 < R2) {  // requested before this slot's stores
           const int kn = fc_opaque(kap) + C::S2 * (k + 1);
           wn = slot_tw<T>(tb, kn);
           const int idn[4] = {kn, N - kn, M - kn, M + kn};
           pn = pre((q * R2 + k + 1) * 4, idn);
-        };
-        if (PIPE == 2 && k + 1 < R2) fetch_next();  // a whole slot ahead of its use
-        T y[4] = {T(0), T(0), T(0), T(0)};
-        if constexpr (FWD) slot_fwd<T>(r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k], w, y[0], y[1], y[2], y[3]);
-        const int idx[4] = {kk, N - kk, M - kk, M + kk};
-        f((q * R2 + k) * 4, idx, y, true, pc);
-        if (PIPE == 1 && k + 1 < R2) fetch_next();  // requested before this slot's stores
+        }
         st((q * R2 + k) * 4, idx, y, true);
-        if constexpr (ADJ) slot_adj<T>(y[0], y[1], y[2], y[3], w, r1[k], i1[k], r2[R2 - 1 - k], i2[R2 - 1 - k]);
+        if constexpr (ADJ) slot_adj<T>(cx_make(y[0], y[1]), cx_make(y[2], y[3]), w, r1[k], r2[R2 - 1 - k]);
       }
       CHS_RSTAMP1(3);
     } else {
@@ -633,7 +615,7 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
       // The special lane: butterfly 0 pairs k <-> R2-k, butterfly S2/2 pairs k <-> R2-1-k.  Its slot
       // s = 1..H-1 works on (r1[s], r1[R2-s]), slot s = H..R2-1 on (r2[s-H], r2[R2-1-(s-H)]); slot 0
       // holds (X[0], X[M/2], X[M], X[3M/2]) from the two self-paired outputs r1[0], r1[H].
-      auto sel = [&](T a, T b) { return sp ? a : b; };
+      auto sel = [&](V a, V b) { return cx_make(sp ? cx_re(a) : cx_re(b), sp ? cx_im(a) : cx_im(b)); };
       auto kk_of = [&](int k) {
         const int kk_s = (k == 0) ? C::S2 : ((k < H) ? C::S2 * k : C::S2 / 2 + C::S2 * (k - H));  // k = 0: unused
         return sp ? kk_s : kap + C::S2 * k;
@@ -667,19 +649,19 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
         }
         T y[4] = {T(0), T(0), T(0), T(0)};
         if constexpr (FWD) {
-          T a0, a1, a2, a3, b0, b1, b2, b3;
-          slot_fwd<T>(r1[0], i1[0], r1[0], i1[0], w0, a0, a1, a2, a3);
-          slot_fwd<T>(r1[H], i1[H], r1[H], i1[H], wh, b0, b1, b2, b3);
-          y[0] = a0; y[1] = b0; y[2] = a2; y[3] = b1;
+          V a01, a23, b01, b23;
+          slot_fwd<T>(r1[0], r1[0], w0, a01, a23);
+          slot_fwd<T>(r1[H], r1[H], wh, b01, b23);
+          y[0] = cx_re(a01); y[1] = cx_re(b01); y[2] = cx_re(a23); y[3] = cx_im(b01);
         }
         f(q * R2 * 4, idx, y, true, p0);
         st(q * R2 * 4, idx, y, true);
         if constexpr (ADJ) {
-          T gar, gai, gzr, gzi;
-          slot_adj<T>(y[0], T(0), y[2], T(0), w0, gar, gai, gzr, gzi);
-          r1[0] = gar + gzr; i1[0] = gai + gzi;
-          slot_adj<T>(y[1], y[3], T(0), T(0), wh, gar, gai, gzr, gzi);
-          r1[H] = gar + gzr; i1[H] = gai + gzi;
+          V ga, gz;
+          slot_adj<T>(cx_make(y[0], T(0)), cx_make(y[2], T(0)), w0, ga, gz);
+          r1[0] = cx_add(ga, gz);
+          slot_adj<T>(cx_make(y[1], y[3]), zero, wh, ga, gz);
+          r1[H] = cx_add(ga, gz);
         }
       }
       CHS_RSTAMP(1);
@@ -695,43 +677,39 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
         }
         const SlotTw<T> w = wn;
         const auto pc = pn;
-        auto fetch_next = [&]() {
+        // operand registers: *_n for every other lane, *_s for the special lane
+        V* a_n = &r1[k]; V* b_n = &r2[R2 - 1 - k];
+        V* a_s = (k < H) ? &r1[k] : &r2[k - H];
+        V* b_s = (k == 0) ? &r2[R2 - 1] : ((k < H) ? &r1[R2 - k] : &r2[R2 - 1 - (k - H)]);
+        V Ya = zero, Yb = zero;
+        if constexpr (FWD) slot_fwd<T>(sel(*a_s, *a_n), sel(*b_s, *b_n), w, Ya, Yb);
+        T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
+        const int idx[4] = {kk, N - kk, M - kk, M + kk};
+        const bool live = (k > 0) || !sp;
+        f((q * R2 + k) * 4, idx, y, live, pc);
+        if (PIPE && k + 1 < R2) {  // requested before this slot's stores
           const int kap_o = fc_opaque(kap);  // (unconditional: an asm in one arm of a select becomes a branch)
           const int kn = sp ? kk_of(k + 1) : kap_o + C::S2 * (k + 1);
           wn = slot_tw<T>(tb, kn);
           const int idn[4] = {kn, N - kn, M - kn, M + kn};
           pn = pre((q * R2 + k + 1) * 4, idn);
-        };
-        if (PIPE == 2 && k + 1 < R2) fetch_next();
-        // operand registers: *_n for every other lane, *_s for the special lane
-        T* ar_n = &r1[k]; T* ai_n = &i1[k]; T* br_n = &r2[R2 - 1 - k]; T* bi_n = &i2[R2 - 1 - k];
-        T* ar_s = (k < H) ? &r1[k] : &r2[k - H];
-        T* ai_s = (k < H) ? &i1[k] : &i2[k - H];
-        T* br_s = (k == 0) ? &r2[R2 - 1] : ((k < H) ? &r1[R2 - k] : &r2[R2 - 1 - (k - H)]);
-        T* bi_s = (k == 0) ? &i2[R2 - 1] : ((k < H) ? &i1[R2 - k] : &i2[R2 - 1 - (k - H)]);
-        T y[4] = {T(0), T(0), T(0), T(0)};
-        if constexpr (FWD)
-          slot_fwd<T>(sel(*ar_s, *ar_n), sel(*ai_s, *ai_n), sel(*br_s, *br_n), sel(*bi_s, *bi_n), w, y[0], y[1], y[2], y[3]);
-        const int idx[4] = {kk, N - kk, M - kk, M + kk};
-        const bool live = (k > 0) || !sp;
-        f((q * R2 + k) * 4, idx, y, live, pc);
-        if (PIPE == 1 && k + 1 < R2) fetch_next();  // requested before this slot's stores
+        }
         st((q * R2 + k) * 4, idx, y, live);
         if constexpr (ADJ) {
-          T nar, nai, nbr, nbi;
-          slot_adj<T>(y[0], y[1], y[2], y[3], w, nar, nai, nbr, nbi);
+          V na, nb;
+          slot_adj<T>(cx_make(y[0], y[1]), cx_make(y[2], y[3]), w, na, nb);
           if (k == 0) {
-            *ar_n = sel(*ar_n, nar); *ai_n = sel(*ai_n, nai);
-            *br_n = sel(*br_n, nbr); *bi_n = sel(*bi_n, nbi);
+            *a_n = sel(*a_n, na);
+            *b_n = sel(*b_n, nb);
           } else {
             if (k < H) {
-              *ar_n = nar; *ai_n = nai;
+              *a_n = na;
             } else {
-              *ar_s = sel(nar, *ar_s); *ai_s = sel(nai, *ai_s);
-              *ar_n = sel(*ar_n, nar); *ai_n = sel(*ai_n, nai);
+              *a_s = sel(na, *a_s);
+              *a_n = sel(*a_n, na);
             }
-            *br_s = sel(nbr, *br_s); *bi_s = sel(nbi, *bi_s);
-            *br_n = sel(*br_n, nbr); *bi_n = sel(*bi_n, nbi);
+            *b_s = sel(nb, *b_s);
+            *b_n = sel(*b_n, nb);
           }
         }
       }
@@ -748,20 +726,18 @@ __device__ __forceinline__ void recombine(typename C::T* re, typename C::T* im, 
 //   b[j] = (Q2.0, Q2.2)   b[R0-1-j] = (Q1.3, Q1.1)      (butterfly m2)
 // ---------------------------------------------------------------------------
 template <class C>
-__device__ __forceinline__ void pack_quads(const typename C::T q1[4], const typename C::T q2[4], int q, int j,
-                                           typename C::T* re, typename C::T* im) {
+__device__ __forceinline__ void pack_quads(const typename C::T q1[4], const typename C::T q2[4], int q, int j, typename C::V* z) {
   constexpr int R0 = C::R0;
-  re[(q * 2 + 0) * R0 + j] = q1[0]; im[(q * 2 + 0) * R0 + j] = q1[2];
-  re[(q * 2 + 1) * R0 + j] = q2[0]; im[(q * 2 + 1) * R0 + j] = q2[2];
-  re[(q * 2 + 1) * R0 + (R0 - 1 - j)] = q1[3]; im[(q * 2 + 1) * R0 + (R0 - 1 - j)] = q1[1];
-  re[(q * 2 + 0) * R0 + (R0 - 1 - j)] = q2[3]; im[(q * 2 + 0) * R0 + (R0 - 1 - j)] = q2[1];
+  z[(q * 2 + 0) * R0 + j] = cx_make(q1[0], q1[2]);
+  z[(q * 2 + 1) * R0 + j] = cx_make(q2[0], q2[2]);
+  z[(q * 2 + 1) * R0 + (R0 - 1 - j)] = cx_make(q1[3], q1[1]);
+  z[(q * 2 + 0) * R0 + (R0 - 1 - j)] = cx_make(q2[3], q2[1]);
 }
 template <class C>
-__device__ __forceinline__ void unpack_quads(const typename C::T* re, const typename C::T* im, int q, int j,
-                                             typename C::T q1[4], typename C::T q2[4]) {
+__device__ __forceinline__ void unpack_quads(const typename C::V* z, int q, int j, typename C::T q1[4], typename C::T q2[4]) {
   constexpr int R0 = C::R0;
-  q1[0] = re[(q * 2 + 0) * R0 + j]; q1[2] = im[(q * 2 + 0) * R0 + j];
-  q2[0] = re[(q * 2 + 1) * R0 + j]; q2[2] = im[(q * 2 + 1) * R0 + j];
-  q1[3] = re[(q * 2 + 1) * R0 + (R0 - 1 - j)]; q1[1] = im[(q * 2 + 1) * R0 + (R0 - 1 - j)];
-  q2[3] = re[(q * 2 + 0) * R0 + (R0 - 1 - j)]; q2[1] = im[(q * 2 + 0) * R0 + (R0 - 1 - j)];
+  q1[0] = cx_re(z[(q * 2 + 0) * R0 + j]); q1[2] = cx_im(z[(q * 2 + 0) * R0 + j]);
+  q2[0] = cx_re(z[(q * 2 + 1) * R0 + j]); q2[2] = cx_im(z[(q * 2 + 1) * R0 + j]);
+  q1[3] = cx_re(z[(q * 2 + 1) * R0 + (R0 - 1 - j)]); q1[1] = cx_im(z[(q * 2 + 1) * R0 + (R0 - 1 - j)]);
+  q2[3] = cx_re(z[(q * 2 + 0) * R0 + (R0 - 1 - j)]); q2[1] = cx_im(z[(q * 2 + 0) * R0 + (R0 - 1 - j)]);
 }

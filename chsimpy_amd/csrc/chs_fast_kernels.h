@@ -182,7 +182,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
   row_lane_map<C>(l, sub);
   const int row = row_of_block<C>(blockIdx.x) + sub;
   T* scr = lds + (size_t)sub * C::SCR;
-  T re[C::E], im[C::E];
+  typename C::V z[C::E];
   double s2 = 0.0;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
   const unsigned urow = (unsigned)row * C::N;  // (32-bit offsets from the uniform base, see tile_boff)
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
       T q1[4], q2[4];
       load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
       load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
-      pack_quads<C>(q1, q2, q, j, re, im);
+      pack_quads<C>(q1, q2, q, j, z);
     }
   }
   if constexpr (POINTWISE) {
@@ -215,11 +215,15 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
       asm volatile("" : "+v"(u), "+v"(s2), "+v"(dom));  // one grid point at a time (register pressure)
     };
 #pragma unroll
-    for (int e = 0; e < C::E; ++e) { mu(re[e]); mu(im[e]); }
+    for (int e = 0; e < C::E; ++e) {
+      T a = cx_re(z[e]), b = cx_im(z[e]);
+      mu(a); mu(b);
+      z[e] = cx_make(a, b);
+    }
     if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of this step becomes NaN
   }
-  fwd_passes<C>(re, im, scr, tb, l);
-  recombine<C, true, false, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
+  fwd_passes<C>(z, scr, tb, l);
+  recombine<C, true, false, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
                             [&](int, const int idx[4], T y[4], bool live, NoFetch) {
     if (live) {
 #pragma unroll
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
     for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
     __syncthreads();
   }
-  T re[C::E], im[C::E];
+  typename C::V z[C::E];
   double s2 = 0.0;
   unsigned dom = 0;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
         T q1[4], q2[4];
         load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
         load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
-        pack_quads<C>(q1, q2, q, j, re, im);
+        pack_quads<C>(q1, q2, q, j, z);
       }
     }
     if (pass == 1) {
@@ -288,12 +292,16 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
         asm volatile("" : "+v"(u), "+v"(s2), "+v"(dom));  // one grid point at a time (register pressure)
       };
 #pragma unroll
-      for (int e = 0; e < C::E; ++e) { mu(re[e]); mu(im[e]); }
+      for (int e = 0; e < C::E; ++e) {
+        T a = cx_re(z[e]), b = cx_im(z[e]);
+        mu(a); mu(b);
+        z[e] = cx_make(a, b);
+      }
       if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of the first step becomes NaN
     }
     T* dst = pass ? T1 : Ta;
-    fwd_passes<C>(re, im, scr, tb, launder(l));
-    recombine<C, true, false, false>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
+    fwd_passes<C>(z, scr, tb, launder(l));
+    recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
                               [&](int, const int idx[4], T y[4], bool live, NoFetch) {
       if (live) {
 #pragma unroll
@@ -339,15 +347,15 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   const int row0 = row_of_block<C>(blockIdx.x);
   const int row = row0 + sub;
   T* scr = lds + (size_t)sub * C::SCR;
-  T re[C::E], im[C::E];
+  typename C::V z[C::E];
   if constexpr (DIAG && FUSE) STAMP(0, 0);
-  recombine<C, false, true, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
+  recombine<C, false, true, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
                             [&](int, const int idx[4], T y[4], bool, NoFetch) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) y[t] = *at_boff(T2, tile_boff<C>(row, idx[t]));
   }, [](int, const int*, T*, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
-  inv_passes<C>(re, im, scr, tb, launder(l));
+  inv_passes<C>(z, scr, tb, launder(l));
   if constexpr (DIAG && FUSE) STAMP(0, 2);
   __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
   const unsigned urow = (unsigned)row * C::N;
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
 #pragma unroll
       for (int j = 0; j < C::R0 / 2; ++j) {
         T q1[4], q2[4];
-        unpack_quads<C>(re, im, q, j, q1, q2);
+        unpack_quads<C>(z, q, j, q1, q2);
         store4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
         store4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
       }
@@ -375,9 +383,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     // np.gradient edge columns: (U[r,1]-U[r,0]) and (U[r,N-1]-U[r,N-2]) live in lane 0
     if (ls == 0) {
       T q1[4], q2[4];
-      unpack_quads<C>(re, im, 0, 0, q1, q2);
+      unpack_quads<C>(z, 0, 0, q1, q2);
       const double d0 = (double)q1[1] - (double)q1[0];
-      unpack_quads<C>(re, im, 0, C::R0 / 2 - 1, q1, q2);
+      unpack_quads<C>(z, 0, C::R0 / 2 - 1, q1, q2);
       const double d1 = (double)q2[3] - (double)q2[2];
       sEdge += d0 * d0 + d1 * d1;
     }
@@ -396,13 +404,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       double rs = 0.0;
       if (mine) {
 #pragma unroll
-        for (int e = 0; e < C::E; ++e) rs += (double)re[e] + (double)im[e];
+        for (int e = 0; e < C::E; ++e) rs += (double)cx_re(z[e]) + (double)cx_im(z[e]);
       }
       const double rmean = block_sum(rs, red) / (double)C::N;
       double ad = 0.0;
       if (mine) {
 #pragma unroll
-        for (int e = 0; e < C::E; ++e) ad += fabs((double)re[e] - rmean) + fabs((double)im[e] - rmean);
+        for (int e = 0; e < C::E; ++e) ad += fabs((double)cx_re(z[e]) - rmean) + fabs((double)cx_im(z[e]) - rmean);
       }
       const double ra = block_sum(ad, red) / (double)C::N;
       if (ra_blk && threadIdx.x == 0) partRa[0] = ra;
@@ -436,8 +444,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     };
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
-      point(re[e]);
-      point(im[e]);
+      T a = cx_re(z[e]), b = cx_im(z[e]);
+      point(a);
+      point(b);
+      z[e] = cx_make(a, b);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (dom > (unsigned)(CHS_LOGTAB_N - 1)) sE = __builtin_nan("");  // U left (0,1): the record of this step becomes NaN
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
 #pragma unroll
               for (int j = h * JH; j < (h + 1) * JH; ++j) {
                 T q1[4], q2[4];
-                unpack_quads<C>(re, im, q, j, q1, q2);  // mu of row `row`, columns 4*(m + L1*j) .. +3
+                unpack_quads<C>(z, q, j, q1, q2);  // mu of row `row`, columns 4*(m + L1*j) .. +3
                 const int c1 = 4 * (m1 + C::L1 * j), c2 = 4 * (m2 + C::L1 * j);
                 const int o1 = c1 - h * (C::N / NH), o2 = c2 - h * (C::N / NH);
 #pragma unroll
@@ -494,10 +504,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   if constexpr (DIAG && FUSE) STAMP(0, 4);
   if constexpr (FUSE) {
     __builtin_amdgcn_sched_barrier(0);
-    fwd_passes<C>(re, im, scr, tb, launder(l));
+    fwd_passes<C>(z, scr, tb, launder(l));
     if constexpr (DIAG && FUSE) STAMP(0, 5);
     __builtin_amdgcn_sched_barrier(0);
-    recombine<C, true, false, false>(re, im, tb, launder(l), [](int, const int*) { return NoFetch{}; },
+    recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
                               [](int, const int*, T*, bool, NoFetch) {},
                               [&](int, const int idx[4], T y[4], bool live) {
       if (live) {
@@ -619,7 +629,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   }
   const int kc = ct * C::CT + hh * C::C + sub;  // this group's column
   T* scr = lds + (size_t)sub * C::SCR;
-  T re[C::E], im[C::E];
+  typename C::V z[C::E];
   // MODE_STEP: the twiddles of the radix passes come from LDS (copied once per workgroup; visible
   // behind the barriers of the stage-in): no L2 round trip per pass, and no load that would have to
   // wait behind the hat_U stores at the start of the inverse passes
@@ -707,13 +717,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
             q1[e] = lds[(m1 + C::L1 * jj) * CS::LP + e * C::C + sub];
             q2[e] = lds[(m2 + C::L1 * jj) * CS::LP + e * C::C + sub];
           }
-          pack_quads<C>(q1, q2, q, j, re, im);
+          pack_quads<C>(q1, q2, q, j, z);
         }
       }
     }
     __syncthreads();
     if constexpr (MODE == MODE_STEP) STAMP(1, 1);
-    fwd_passes<C>(re, im, scr, tbp, l);
+    fwd_passes<C>(z, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 2);
     if constexpr (MODE == MODE_STEP) {
       // Gated tail: the bookkeeping of the previous step -- stop rules, adaptive time step -- runs as block 0
@@ -732,7 +742,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   constexpr bool FWD = (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE);
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL || MODE == MODE_INV_NATIVE);
   if constexpr (MODE == MODE_STEP) {
-    recombine<C, true, true, true>(re, im, tb, l, fetch,
+    recombine<C, true, true, true>(z, tb, l, fetch,
       [&](int pbase, const int*, T y[4], bool live, const Fetched& p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -752,7 +762,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         }
       });
   } else {
-    recombine<C, FWD, ADJ, false>(re, im, tb, l, [](int, const int*) { return NoFetch{}; },
+    recombine<C, FWD, ADJ, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
                            [&](int pbase, const int idx[4], T y[4], bool live, NoFetch) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -776,7 +786,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   }
   if constexpr (MODE == MODE_STEP) STAMP(1, 3);
   if constexpr (ADJ) {
-    inv_passes<C>(re, im, scr, tbp, l);
+    inv_passes<C>(z, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 4);
     // ---- stage out: quads -> tile rows
     T* tile = Tout + (size_t)ct * C::N * C::CT;
@@ -790,7 +800,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         for (int jj = 0; jj < CS::JR; ++jj) {
           const int j = rho * CS::JR + jj;
           T q1[4], q2[4];
-          unpack_quads<C>(re, im, q, j, q1, q2);
+          unpack_quads<C>(z, q, j, q1, q2);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             lds[(m1 + C::L1 * jj) * CS::LP + e * C::C + sub] = q1[e];
