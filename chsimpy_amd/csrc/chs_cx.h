@@ -132,6 +132,23 @@ template <class V> __device__ __forceinline__ V cx_mul_k(V a, V k) {
   return pk_fma_k<1, 1, 1, 0, 0, 0, 1, 0>(a, k, t);
 }
 
+// fp32: the two instructions of a complex product in ONE asm statement.  hipcc assumes that the result of an asm
+// statement may be subject to the dst-sel forwarding hazard and puts an s_nop in front of an instruction that reads
+// it right away (here it is not: full 32-bit writes); inside one statement the dependent pair issues back to back.
+#define CHS_CX_MUL2(NAME, MULMODS, FMAMODS, KC)                                                          \
+  __device__ __forceinline__ v2f NAME(v2f a, v2f w) {                                                    \
+    v2f d;                                                                                                \
+    asm("v_pk_mul_f32 %0, %1, %2 " MULMODS "\n\tv_pk_fma_f32 %0, %1, %2, %0 " FMAMODS                     \
+        : "=&v"(d) : "v"(a), KC(w));                                                                      \
+    return d;                                                                                             \
+  }
+//                    t = (ar wr, +-ar wi)                         d = (+-ai wi + t.x, +-ai wr + t.y)
+CHS_CX_MUL2(cx_mul,    "op_sel_hi:[0,1]",              "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]", "v")
+CHS_CX_MUL2(cx_mulc,   "op_sel_hi:[0,1] neg_hi:[0,1]", "op_sel:[1,1,0] op_sel_hi:[1,0,1]", "v")
+CHS_CX_MUL2(cx_mul_cj, "op_sel_hi:[0,1] neg_hi:[0,1]", "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]", "v")
+CHS_CX_MUL2(cx_mul_k,  "op_sel_hi:[0,1]",              "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]", "s")
+#undef CHS_CX_MUL2
+
 // (r, i) of a value as scalars
 __device__ __forceinline__ double cx_re(D2 a) { return a.x; }
 __device__ __forceinline__ double cx_im(D2 a) { return a.y; }

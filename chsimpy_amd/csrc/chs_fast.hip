@@ -64,8 +64,6 @@ static int build_tables(Engine* E, FastPlan* P) {
   for (int kk = 0; kk <= M; ++kk) { long double r, i; Tk(kk, r, i); push(r, i); }
   P->off_t2 = h.size();
   for (int kk = 0; kk <= M; ++kk) { long double r, i; Tk(M - kk, r, i); push(r, -i); }
-  CHS_HIP(hipMalloc(&P->tables, h.size() * sizeof(T)));
-  CHS_HIP(hipMemcpy(P->tables, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   // interleaved {lambda_k, sin^2(pi k/N)}: the eigenvalue table of utils.py:35 next to the weights of
   // the spectral form of np.gradient's sum of squares -- one 16-byte load per coefficient
   std::vector<double> lam(N), sq(2 * (size_t)N);
@@ -75,6 +73,20 @@ static int build_tables(Engine* E, FastPlan* P) {
     sq[2 * k] = lam[k];
     sq[2 * k + 1] = (double)(v * v);
   }
+  // per-slot entries of the same two quantities for the packed fp32 spectral stage (FTables::lam4 / sin4): the four
+  // coefficients {j, N-j, M-j, M+j} of slot j = 0..M (out-of-range ones only occur in slots that are never live),
+  // and entry M+1 for the special lane's own slot {0, M/2, M, 3M/2}; 16-byte aligned inside the table buffer
+  while (h.size() % 4) h.push_back((T)0);
+  P->off_lam4 = h.size();
+  auto quad = [&](int j, int t) { const int q[4] = {j, N - j, M - j, M + j}; return q[t] < 0 ? 0 : (q[t] > N - 1 ? N - 1 : q[t]); };
+  const int own[4] = {0, M / 2, M, 3 * (M / 2)};
+  for (int j = 0; j <= M + 1; ++j)
+    for (int t = 0; t < 4; ++t) h.push_back((T)lam[j <= M ? quad(j, t) : own[t]]);
+  P->off_sin4 = h.size();
+  for (int j = 0; j <= M + 1; ++j)
+    for (int t = 0; t < 4; ++t) h.push_back((T)sq[2 * (j <= M ? quad(j, t) : own[t]) + 1]);
+  CHS_HIP(hipMalloc(&P->tables, h.size() * sizeof(T)));
+  CHS_HIP(hipMemcpy(P->tables, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   CHS_HIP(hipMalloc(&E->dSinSq, sizeof(double) * 2 * N));
   CHS_HIP(hipMemcpy(E->dSinSq, sq.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice));
   return CHS_OK;

@@ -82,6 +82,11 @@ struct FTables {
   const T* wp;   // [kk] = -i exp(-2 pi i kk / N),          kk = 0..M
   const T* t1;   // [kk] = s_kk/2 exp(-i pi kk/(2N))
   const T* t2;   // [kk] = conj(s_(M-kk)/2 exp(-i pi (M-kk)/(2N)))
+  // fp32 engine, k_col's spectral stage: the eigenvalues and gradient weights of a recombination slot's four
+  // coefficients {kk, N-kk, M-kk, M+kk} as ONE 16-byte entry each, so that they arrive as the two register
+  // pairs the packed arithmetic wants; entry M+1 = the special lane's own slot {0, M/2, M, 3M/2}
+  const T* lam4;  // [4*j + t] = lambda of coefficient t of slot j (utils.py:35)
+  const T* sin4;  // [4*j + t] = sin^2(pi k_t / N)
 };
 
 // ---------------------------------------------------------------------------
@@ -271,6 +276,12 @@ struct Own {
     return t == 0 ? kk : (t == 1 ? C::N - kk : (t == 2 ? C::M - kk : C::M + kk));
   }
 };
+
+template <typename T>
+__device__ __forceinline__ void stc(T* __restrict__ tab, int idx, Cx<T> v) {
+  if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(tab + 2 * (size_t)idx) = make_double2(v.x, v.y);
+  else *reinterpret_cast<v2f*>(tab + 2 * (size_t)idx) = v;
+}
 
 // ---------------------------------------------------------------------------
 // recombination slot and its adjoint (tools/dct_model.py: slot_fwd / slot_adj)
@@ -523,12 +534,12 @@ __device__ __forceinline__ void inv_passes(typename C::V* z, typename C::T* scr,
 
 // ===========================================================================
 // Recombination stage, in place on the last-pass registers.
-//   FWD: (A, Z) -> y[4] = the four real coefficients of the slot (slot_fwd)
-//   f(pbase, idx, y): the caller consumes / replaces y.  pbase = (q*R2 + k)*4 is the
-//        compile-time position of the slot, idx[t] the coefficient index of y[t]
-//        (Own::out_index).
-//   ADJ: y[4] -> (gA, gZ) written back over (A, Z) (slot_adj)
-// With FWD only the registers are left untouched; with ADJ only y comes from f.
+//   FWD: (A, Z) -> Ya = (y0, y1), Yb = (y2, y3): the four real coefficients of the slot (slot_fwd)
+//   f(pbase, idx, Ya, Yb, live, fetched): the caller consumes / replaces them.  pbase = (q*R2 + k)*4 is the
+//        compile-time position of the slot, idx[t] the coefficient index of y_t (Own::out_index), idx[4] the
+//        slot's entry in per-slot tables: kk, or M + 1 for the special lane's own slot (indices 0, M/2, M, 3M/2).
+//   ADJ: (Ya, Yb) -> (gA, gZ) written back over (A, Z) (slot_adj)
+// With FWD only the registers are left untouched; with ADJ only Ya, Yb come from f.
 // ===========================================================================
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
 template <int I0, int I1, class F>
@@ -576,7 +587,7 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
     if (q == 0) has_special = (C::G < 64) || (__builtin_amdgcn_readfirstlane(l) == 0);  // (the wavefront that holds butterfly 0)
     if (!has_special) {
       SlotTw<T> wn;
-      const int id0[4] = {kap, N - kap, M - kap, M + kap};
+      const int id0[5] = {kap, N - kap, M - kap, M + kap, kap};
       decltype(pre(0, id0)) pn;
       if constexpr (PIPE) {
         wn = slot_tw<T>(tb, kap);
@@ -590,24 +601,23 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
         const int kk = kap + C::S2 * k;
         if (!PIPE) {
           wn = slot_tw<T>(tb, kk);
-          const int idc[4] = {kk, N - kk, M - kk, M + kk};
+          const int idc[5] = {kk, N - kk, M - kk, M + kk, kk};
           pn = pre((q * R2 + k) * 4, idc);
         }
         const SlotTw<T> w = wn;  // shared by the forward and the adjoint half
         const auto pc = pn;
         V Ya = zero, Yb = zero;
         if constexpr (FWD) slot_fwd<T>(r1[k], r2[R2 - 1 - k], w, Ya, Yb);
-        T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
-        const int idx[4] = {kk, N - kk, M - kk, M + kk};
-        f((q * R2 + k) * 4, idx, y, true, pc);
+        const int idx[5] = {kk, N - kk, M - kk, M + kk, kk};
+        f((q * R2 + k) * 4, idx, Ya, Yb, true, pc);
         if (PIPE && k + 1 < R2) {  // requested before this slot's stores
           const int kn = fc_opaque(kap) + C::S2 * (k + 1);
           wn = slot_tw<T>(tb, kn);
-          const int idn[4] = {kn, N - kn, M - kn, M + kn};
+          const int idn[5] = {kn, N - kn, M - kn, M + kn, kn};
           pn = pre((q * R2 + k + 1) * 4, idn);
         }
-        st((q * R2 + k) * 4, idx, y, true);
-        if constexpr (ADJ) slot_adj<T>(cx_make(y[0], y[1]), cx_make(y[2], y[3]), w, r1[k], r2[R2 - 1 - k]);
+        st((q * R2 + k) * 4, idx, Ya, Yb, true);
+        if constexpr (ADJ) slot_adj<T>(Ya, Yb, w, r1[k], r2[R2 - 1 - k]);
       }
       CHS_RSTAMP1(3);
     } else {
@@ -628,7 +638,7 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
       // used to fetch on its own, with nothing to overlap the wait).
       const int o1 = PIPE ? (sp ? 0 : kk0) : kk0, o2 = PIPE ? (sp ? M / 2 : N - kk0) : N - kk0;
       const int o3 = PIPE ? (sp ? M : M - kk0) : M - kk0, o4 = PIPE ? (sp ? 3 * (M / 2) : M + kk0) : M + kk0;
-      const int id0[4] = {o1, o2, o3, o4};
+      const int id0[5] = {o1, o2, o3, o4, (PIPE && sp) ? M + 1 : kk0};
       decltype(pre(0, id0)) pn;
       SlotTw<T> whp = SlotTw<T>();
       if constexpr (PIPE) {  // slot 0 of the loop below, requested ahead of the special lane's own slot
@@ -638,7 +648,7 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
       }
       CHS_RSTAMP(0);
       if (sp) {
-        const int idx[4] = {0, M / 2, M, 3 * (M / 2)};
+        const int idx[5] = {0, M / 2, M, 3 * (M / 2), M + 1};
         SlotTw<T> w0, wh;
         decltype(pre(0, id0)) p0;
         if constexpr (PIPE) {
@@ -647,20 +657,21 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
           w0 = slot_tw<T>(tb, 0); wh = slot_tw<T>(tb, M / 2);
           p0 = pre(q * R2 * 4, idx);
         }
-        T y[4] = {T(0), T(0), T(0), T(0)};
+        V Ya = zero, Yb = zero;
         if constexpr (FWD) {
           V a01, a23, b01, b23;
           slot_fwd<T>(r1[0], r1[0], w0, a01, a23);
           slot_fwd<T>(r1[H], r1[H], wh, b01, b23);
-          y[0] = cx_re(a01); y[1] = cx_re(b01); y[2] = cx_re(a23); y[3] = cx_im(b01);
+          Ya = cx_make(cx_re(a01), cx_re(b01));
+          Yb = cx_make(cx_re(a23), cx_im(b01));
         }
-        f(q * R2 * 4, idx, y, true, p0);
-        st(q * R2 * 4, idx, y, true);
+        f(q * R2 * 4, idx, Ya, Yb, true, p0);
+        st(q * R2 * 4, idx, Ya, Yb, true);
         if constexpr (ADJ) {
           V ga, gz;
-          slot_adj<T>(cx_make(y[0], T(0)), cx_make(y[2], T(0)), w0, ga, gz);
+          slot_adj<T>(cx_make(cx_re(Ya), T(0)), cx_make(cx_re(Yb), T(0)), w0, ga, gz);
           r1[0] = cx_add(ga, gz);
-          slot_adj<T>(cx_make(y[1], y[3]), zero, wh, ga, gz);
+          slot_adj<T>(cx_make(cx_im(Ya), cx_im(Yb)), zero, wh, ga, gz);
           r1[H] = cx_add(ga, gz);
         }
       }
@@ -672,7 +683,7 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
         const int kk = kk_of(k);
         if (!PIPE) {
           wn = slot_tw<T>(tb, kk);
-          const int idc[4] = {kk, N - kk, M - kk, M + kk};
+          const int idc[5] = {kk, N - kk, M - kk, M + kk, kk};
           pn = pre((q * R2 + k) * 4, idc);
         }
         const SlotTw<T> w = wn;
@@ -683,21 +694,20 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
         V* b_s = (k == 0) ? &r2[R2 - 1] : ((k < H) ? &r1[R2 - k] : &r2[R2 - 1 - (k - H)]);
         V Ya = zero, Yb = zero;
         if constexpr (FWD) slot_fwd<T>(sel(*a_s, *a_n), sel(*b_s, *b_n), w, Ya, Yb);
-        T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
-        const int idx[4] = {kk, N - kk, M - kk, M + kk};
+        const int idx[5] = {kk, N - kk, M - kk, M + kk, kk};
         const bool live = (k > 0) || !sp;
-        f((q * R2 + k) * 4, idx, y, live, pc);
+        f((q * R2 + k) * 4, idx, Ya, Yb, live, pc);
         if (PIPE && k + 1 < R2) {  // requested before this slot's stores
           const int kap_o = fc_opaque(kap);  // (unconditional: an asm in one arm of a select becomes a branch)
           const int kn = sp ? kk_of(k + 1) : kap_o + C::S2 * (k + 1);
           wn = slot_tw<T>(tb, kn);
-          const int idn[4] = {kn, N - kn, M - kn, M + kn};
+          const int idn[5] = {kn, N - kn, M - kn, M + kn, kn};
           pn = pre((q * R2 + k + 1) * 4, idn);
         }
-        st((q * R2 + k) * 4, idx, y, live);
+        st((q * R2 + k) * 4, idx, Ya, Yb, live);
         if constexpr (ADJ) {
           V na, nb;
-          slot_adj<T>(cx_make(y[0], y[1]), cx_make(y[2], y[3]), w, na, nb);
+          slot_adj<T>(Ya, Yb, w, na, nb);
           if (k == 0) {
             *a_n = sel(*a_n, na);
             *b_n = sel(*b_n, nb);

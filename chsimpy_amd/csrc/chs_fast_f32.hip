@@ -17,8 +17,18 @@
 #ifndef CHS_F32_CT
 #define CHS_F32_CT 8  // columns per tile of the fp32 T layout at N >= 4096: 32-byte row pieces as in fp64 (4: N=8192 23 % slower)
 #endif
-using G8192 = FCfg<float, 8192, 256, CHS_G8192_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT>;
-using G8192C = FCfg<float, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
+#ifndef CHS_G8192_G
+#define CHS_G8192_G 256     // lanes per transform: 256 = 16 complex values per lane, 128 = 32 (the shape of fp64 N=4096)
+#endif
+#ifndef CHS_G8192C_THREADS
+#define CHS_G8192C_THREADS 512
+#endif
+#ifndef CHS_G8192C_TW_LDS
+#define CHS_G8192C_TW_LDS 1
+#endif
+using G8192 = FCfg<float, 8192, CHS_G8192_G, CHS_G8192_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT>;
+using G8192C = FCfg<float, 8192, CHS_G8192_G, CHS_G8192C_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
+template <> struct ColTwLds<G8192C> { static constexpr bool value = (CHS_G8192C_TW_LDS != 0); };
 #ifndef CHS_G4096_THREADS
 #define CHS_G4096_THREADS 256
 #endif

@@ -54,6 +54,10 @@ using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, CHS_PAD1, CHS
 #endif
 // k_col: CHS_COL_THREADS/128 of the 4 columns of a tile per workgroup
 using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, CHS_PAD1, CHS_PAD2, CHS_COL_PADL, CHS_COL_WPS, CHS_F4096_CT>;
+#ifndef CHS_F4096C_TW_LDS
+#define CHS_F4096C_TW_LDS 1
+#endif
+template <> struct ColTwLds<F4096C> { static constexpr bool value = (CHS_F4096C_TW_LDS != 0); };
 
 // fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
 // two rows or two of a tile's four columns per 512-thread workgroup)

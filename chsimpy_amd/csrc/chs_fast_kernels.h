@@ -19,8 +19,10 @@
 // per tile, so a column tile is one contiguous slab (k_col streams it with 16-byte
 // coalesced accesses through an LDS stage) while the row kernels touch it in C*8-byte
 // pieces, four consecutive rows (one workgroup) completing each 128-byte line.
-// hat_U lives in k_col's native order: for column kc, position p of lane l at
-// kc*N + p*G + l -- nobody else reads it.
+// hat_U lives in k_col's native order: column kc at kc*N, inside it the lane's positions in PAIRS -- positions
+// (2j, 2j+1) of lane l are the two components of the value pair number j*G + l (hat_pair_index): a recombination
+// slot's four coefficients are two 16-byte (fp64) / 8-byte (fp32) accesses per lane, contiguous across the
+// lanes of a group -- nobody else reads it.
 #pragma once
 #include <cmath>
 #include <vector>
@@ -144,6 +146,13 @@ __device__ __forceinline__ void store4(T* p, const T q[4]) {
   }
 }
 
+// index (in value pairs, from the column's start) of positions (pbase, pbase+1) of lane l; (pbase+2, pbase+3)
+// follow G pairs later
+template <class C>
+__device__ __forceinline__ int hat_pair_index(int pbase, int l) {
+  return (pbase / 2) * C::G + l;
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 
 // Build knobs that remain (everything else that was tried is recorded with its measurement in DESIGN.md section 7):
@@ -224,12 +233,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
   }
   fwd_passes<C>(z, scr, tb, l);
   recombine<C, true, false, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
-                            [&](int, const int idx[4], T y[4], bool live, NoFetch) {
+                            [&](int, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
     if (live) {
+      const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
 #pragma unroll
       for (int t = 0; t < 4; ++t) *at_boff(T1, tile_boff<C>(row, idx[t])) = y[t];
     }
-  }, [](int, const int*, T*, bool) {});
+  }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (POINTWISE) {
     const double tot = block_sum(s2, red);
     if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
@@ -302,12 +312,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
     T* dst = pass ? T1 : Ta;
     fwd_passes<C>(z, scr, tb, launder(l));
     recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
-                              [&](int, const int idx[4], T y[4], bool live, NoFetch) {
+                              [&](int, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
       if (live) {
+        const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
 #pragma unroll
         for (int t = 0; t < 4; ++t) *at_boff(dst, tile_boff<C>(launder(row), idx[t])) = y[t];
       }
-    }, [](int, const int*, T*, bool) {});
+    }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
     __builtin_amdgcn_sched_barrier(0);
   }
   const double tot = block_sum(s2, red);
@@ -350,10 +361,12 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   typename C::V z[C::E];
   if constexpr (DIAG && FUSE) STAMP(0, 0);
   recombine<C, false, true, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
-                            [&](int, const int idx[4], T y[4], bool, NoFetch) {
+                            [&](int, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool, NoFetch) {
+    T y[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) y[t] = *at_boff(T2, tile_boff<C>(row, idx[t]));
-  }, [](int, const int*, T*, bool) {});
+    Ya = cx_make(y[0], y[1]); Yb = cx_make(y[2], y[3]);
+  }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
   inv_passes<C>(z, scr, tb, launder(l));
   if constexpr (DIAG && FUSE) STAMP(0, 2);
@@ -508,9 +521,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     if constexpr (DIAG && FUSE) STAMP(0, 5);
     __builtin_amdgcn_sched_barrier(0);
     recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
-                              [](int, const int*, T*, bool, NoFetch) {},
-                              [&](int, const int idx[4], T y[4], bool live) {
+                              [](int, const int*, Cx<T>&, Cx<T>&, bool, NoFetch) {},
+                              [&](int, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live) {
       if (live) {
+        const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
 #pragma unroll
         for (int t = 0; t < 4; ++t) *at_boff(T1, tile_boff<C>(row, idx[t])) = y[t];
       }
@@ -568,6 +582,11 @@ template <class C>
 constexpr int col_tw_elems() {
   return 2 * ((C::R0 - 1) * C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
 }
+
+// k_col<MODE_STEP> keeps the pass twiddles in LDS unless a configuration says otherwise (chs_fast_f32.hip: where they
+// would cost the second workgroup of a CU)
+template <class C>
+struct ColTwLds { static constexpr bool value = true; };
 
 template <class C>
 constexpr int col_lds_elems() {
@@ -634,7 +653,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // behind the barriers of the stage-in): no L2 round trip per pass, and no load that would have to
   // wait behind the hat_U stores at the start of the inverse passes
   FTables<T> tbp = tb;
-  if constexpr (MODE == MODE_STEP) {
+  if constexpr (MODE == MODE_STEP && ColTwLds<C>::value) {
     T* ltw = lds + col_lds_elems<C>();
     constexpr int NTW = col_tw_elems<C>();
     for (int i = 2 * threadIdx.x; i < NTW; i += 2 * C::THREADS) {
@@ -657,15 +676,23 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   const double lc = lam[kc_u];
   const double sqc = (MODE == MODE_STEP) ? sinsq[2 * kc_u + 1] : 0.0;
   // What the spectral stage reads per recombination slot (4 positions of this lane), fetched one slot
-  // ahead: {lambda_kr, sin^2(pi kr/N)} from the table (L2) and hat_U.
-  struct Fetched { double2 ls[4]; T h[4]; };
-  auto fetch = [&](int pbase, const int idx[4]) {
+  // ahead: hat_U (two value pairs) and the eigenvalues / gradient weights of its four coefficients -- fp64:
+  // {lambda_kr, sin^2(pi kr/N)} per coefficient (L2); fp32: one 16-byte entry of each per slot (FTables::lam4, sin4).
+  struct Fetched64 { double2 ls[4]; Cx<T> h01, h23; };
+  struct Fetched32 { float4 la, sa; Cx<T> h01, h23; };
+  using Fetched = typename std::conditional<sizeof(T) == 8, Fetched64, Fetched32>::type;
+  auto fetch = [&](int pbase, const int* idx) {
     Fetched p;
+    if constexpr (sizeof(T) == 8) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];
-    const T* hl = hcol + fc_opaque(l);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) p.h[t] = hl[(size_t)(pbase + t) * C::G];
+      for (int t = 0; t < 4; ++t) p.ls[t] = reinterpret_cast<const double2*>(sinsq)[idx[t]];
+    } else {
+      p.la = reinterpret_cast<const float4*>(tb.lam4)[idx[4]];
+      p.sa = reinterpret_cast<const float4*>(tb.sin4)[idx[4]];
+    }
+    const int hp = hat_pair_index<C>(pbase, fc_opaque(l));
+    p.h01 = ldc<T>(hcol, hp);
+    p.h23 = ldc<T>(hcol, hp + C::G);
     return p;
   };
   if constexpr (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE) {
@@ -741,44 +768,77 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   T h00 = T(0);
   constexpr bool FWD = (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE);
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL || MODE == MODE_INV_NATIVE);
+  [[maybe_unused]] v2f e2v = {0.0f, 0.0f};  // fp32: the lane's share of the gradient sum, in two packed halves
   if constexpr (MODE == MODE_STEP) {
+    // fp32: the coefficients of this launch as floats (after the gate: lam1/lam2 are this step's)
+    [[maybe_unused]] const float lam1f = (float)lam1, lam2f = (float)lam2, lcf = (float)lc, sqcf = (float)sqc;
     recombine<C, true, true, true>(z, tb, l, fetch,
-      [&](int pbase, const int*, T y[4], bool live, const Fetched& p) {
+      [&](int pbase, const int*, Cx<T>& Ya, Cx<T>& Yb, bool live, const Fetched& p) {
+        if constexpr (sizeof(T) == 8) {
+          T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
+          const T hold[4] = {cx_re(p.h01), cx_im(p.h01), cx_re(p.h23), cx_im(p.h23)};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const T h = chs_spectral<T, (C::N >= CHS_F32_SPECTRAL_MIN_N)>(p.h[t], y[t], p.ls[t].x, lc, lam1, lam2);
-          y[t] = h;
-          const double term = (double)h * (double)h * (p.ls[t].y + sqc);
-          e2 += live ? term : 0.0;
-          if (pbase + t == 0 && live) h00 = h;  // lane 0 holds kr = 0 at position 0 (its own slot)
+          for (int t = 0; t < 4; ++t) {
+            const T h = chs_spectral<T>(hold[t], y[t], p.ls[t].x, lc, lam1, lam2);
+            y[t] = h;
+            const double term = (double)h * (double)h * (p.ls[t].y + sqc);
+            e2 += live ? term : 0.0;
+            if (pbase + t == 0 && live) h00 = h;  // lane 0 holds kr = 0 at position 0 (its own slot)
+          }
+          asm volatile("" : "+v"(e2));  // do not postpone the 2E energy terms
+          Ya = cx_make(y[0], y[1]); Yb = cx_make(y[2], y[3]);
+        } else {
+          // the semi-implicit update (solver.py:201-206) on value pairs, in single precision like its operands
+          // and its result (chs_spectral_f32 is the scalar form): reciprocal + residual correction
+          auto upd = [&](v2f hold, v2f y, v2f lamr, v2f sr) {
+            const v2f leig = lamr + lcf;
+            const v2f CHeig = __builtin_elementwise_fma(lam2f * leig, leig, v2f{1.0f, 1.0f});
+            const v2f rhs = __builtin_elementwise_fma(lam1f * leig, y, hold);
+            v2f r;
+            r.x = __builtin_amdgcn_rcpf(CHeig.x); r.y = __builtin_amdgcn_rcpf(CHeig.y);
+            const v2f q = rhs * r;
+            const v2f rho = __builtin_elementwise_fma(-CHeig, q, rhs);
+            const v2f h = __builtin_elementwise_fma(rho, r, q);
+            v2f term = (h * h) * (sr + sqcf);
+            if (!live) term = v2f{0.0f, 0.0f};
+            e2v += term;
+            return h;
+          };
+          Ya = upd(p.h01, Ya, v2f{p.la.x, p.la.y}, v2f{p.sa.x, p.sa.y});
+          Yb = upd(p.h23, Yb, v2f{p.la.z, p.la.w}, v2f{p.sa.z, p.sa.w});
+          if (pbase == 0 && live) h00 = Ya.x;  // lane 0 holds kr = 0 at position 0 (its own slot)
         }
-        asm volatile("" : "+v"(e2));  // do not postpone the 2E energy terms
       },
-      [&](int pbase, const int*, T y[4], bool live) {
+      [&](int pbase, const int*, Cx<T>& Ya, Cx<T>& Yb, bool live) {
         if (live) {
-          T* hl = hout + fc_opaque(l);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) hl[(size_t)(pbase + t) * C::G] = y[t];
+          const int hp = hat_pair_index<C>(pbase, fc_opaque(l));
+          stc<T>(hout, hp, Ya);
+          stc<T>(hout, hp + C::G, Yb);
         }
       });
+    if constexpr (sizeof(T) == 4) e2 = (double)e2v.x + (double)e2v.y;
   } else {
     recombine<C, FWD, ADJ, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
-                           [&](int pbase, const int idx[4], T y[4], bool live, NoFetch) {
+                           [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
+      [[maybe_unused]] const int hp = hat_pair_index<C>(pbase, l);
+      if constexpr (MODE == MODE_FWD_NATIVE) {
+        if (live) { stc<T>(hcol, hp, Ya); stc<T>(hcol, hp + C::G, Yb); }
+      } else if constexpr (MODE == MODE_INV_NATIVE) {
+        Ya = ldc<T>(hcol, hp); Yb = ldc<T>(hcol, hp + C::G);  // hat_U as MODE_STEP left it: the column half of U = idctn(hat_U)
+      } else {
+        T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int kr = idx[t];
-        const size_t hp = (size_t)(pbase + t) * C::G + l;
-        if constexpr (MODE == MODE_FWD_NATIVE) {
-          if (live) hcol[hp] = y[t];
-        } else if constexpr (MODE == MODE_FWD_NATURAL) {
-          if (live) nat[(size_t)kr * C::N + kc] = y[t];
-        } else if constexpr (MODE == MODE_INV_NATIVE) {
-          y[t] = hcol[hp];  // hat_U as MODE_STEP left it: the column half of U = idctn(hat_U)
-        } else {
-          y[t] = nat[(size_t)kr * C::N + kc];
+        for (int t = 0; t < 4; ++t) {
+          const int kr = idx[t];
+          if constexpr (MODE == MODE_FWD_NATURAL) {
+            if (live) nat[(size_t)kr * C::N + kc] = y[t];
+          } else {
+            y[t] = nat[(size_t)kr * C::N + kc];
+          }
         }
+        if constexpr (MODE != MODE_FWD_NATURAL) { Ya = cx_make(y[0], y[1]); Yb = cx_make(y[2], y[3]); }
       }
-    }, [](int, const int*, T*, bool) {});
+    }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   }
   if constexpr (MODE == MODE_STEP) STAMP(1, 5);
   if constexpr (MODE == MODE_STEP) {
@@ -843,7 +903,7 @@ enum { ROW_INV_PLAIN = 0, ROW_INV_DIAG = 1, ROW_INV_FUSED = 2, ROW_INV_FUSED_ADA
 struct FastPlan {
   int N, G, R0, RA, RB, RL, threads, col_tiles;
   void* tables = nullptr;  // one device allocation
-  size_t off_tw0, off_twa, off_twb, off_wp, off_t1, off_t2;  // element offsets
+  size_t off_tw0, off_twa, off_twb, off_wp, off_t1, off_t2, off_lam4 = 0, off_sin4 = 0;  // element offsets
   int (*row_fwd)(Engine*, const void*, void*, bool) = nullptr;
   int (*row_fwd2)(Engine*, const void*, void*, void*) = nullptr;
   int (*row_inv)(Engine*, int, const void*, void*, void*) = nullptr;
@@ -858,6 +918,7 @@ static FTables<T> get_tables(Engine* E) {
   FTables<T> tb;
   tb.tw0 = base + P->off_tw0; tb.twa = base + P->off_twa; tb.twb = base + P->off_twb; tb.wp = base + P->off_wp;
   tb.t1 = base + P->off_t1; tb.t2 = base + P->off_t2;
+  tb.lam4 = base + P->off_lam4; tb.sin4 = base + P->off_sin4;
   return tb;
 }
 
@@ -868,7 +929,7 @@ struct Launch {
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
   static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && (C::R0 % 4 == 0);
   // staging / exchange scratch + the pass twiddles (k_col<MODE_STEP>)
-  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (size_t)col_tw_elems<CC>()) * sizeof(T);
+  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (ColTwLds<CC>::value ? (size_t)col_tw_elems<CC>() : 0)) * sizeof(T);
   static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
 
   template <class K>
