@@ -27,7 +27,7 @@ DTYPES = {'float64': CHS_F64, 'f64': CHS_F64, 'float32': CHS_F32, 'f32': CHS_F32
 
 # every symbol include/chs_hip.h declares
 SYMBOLS = (
-    'chs_create', 'chs_destroy', 'chs_pool_clear', 'chs_set_U', 'chs_init_U_pcg64', 'chs_get_U', 'chs_prepare', 'chs_step_n',
+    'chs_create', 'chs_destroy', 'chs_pool_clear', 'chs_pool_count', 'chs_set_U', 'chs_init_U_pcg64', 'chs_get_U', 'chs_prepare', 'chs_step_n',
     'chs_get_state', 'chs_set_state', 'chs_set_jitter_noise', 'chs_set_jitter_pcg64', 'chs_dctn', 'chs_get_mu', 'chs_test_math',
     'chs_engine', 'chs_kernel_name', 'chs_profile_steps', 'chs_last_step_ms',
     'chs_last_error', 'chs_version',
@@ -103,6 +103,11 @@ def load():
 def pool_clear():
     """Free the engines `chs_destroy` has parked for reuse (include/chs_hip.h: chs_pool_clear)."""
     load().chs_pool_clear()
+
+
+def pool_count():
+    """Number of engines parked for reuse right now."""
+    return int(load().chs_pool_count())
 
 
 def _dptr(a):

@@ -147,6 +147,10 @@ size_t engine_bytes(const Engine* E) {
 }
 // Frees every parked engine (the process's only library-owned state besides the handles): for a caller that
 // is done with a device, and registered by the Python binding to run at interpreter exit.
+extern "C" int chs_pool_count(void) {
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  return (int)g_pool.size();
+}
 extern "C" int chs_pool_clear(void) {
   std::vector<Engine*> all;
   {
@@ -513,7 +517,8 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   // EnergieEut(U) and its sum of squares on the device, and a call that finds them continues the loop where it
   // stopped -- hat_U is the array the reference would recompute as dctn(idctn(hat_U)) (solver.py:159), equal up
   // to rounding; CHS_STEP_REDERIVE_HAT asks for the literal recomputation.
-  E->keepResident = fused && !E->dc.adaptive_time && !profile && !(flags & CHS_STEP_LAST_CALL);
+  // (a caller that asks for the literal re-derivation does so at every call: nothing to keep for it either)
+  E->keepResident = fused && !E->dc.adaptive_time && !profile && !(flags & (CHS_STEP_LAST_CALL | CHS_STEP_REDERIVE_HAT));
   const bool cont = fused && E->resident && E->hat_valid && !(flags & CHS_STEP_REDERIVE_HAT) && !profile;
   if (nsteps > 0) E->resident = false;
   if (cont && nsteps > 0) {

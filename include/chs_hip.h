@@ -109,8 +109,9 @@ typedef struct chs_handle_s* chs_handle;
  * its decision, so that the waiting workgroups run into their bounded timeout -> chs_step_n returns CHS_EHIP. */
 int chs_create(const chs_consts* consts, const double* lambda, chs_handle* out);
 int chs_destroy(chs_handle h);
-/* Free every parked engine of this process (all devices). */
+/* Free every parked engine of this process (all devices); chs_pool_count: how many are parked right now. */
 int chs_pool_clear(void);
+int chs_pool_count(void);
 
 /* Upload the N x N row-major float64 field (the reference's U_init / solution.U).
  * Replaces `U = self.U_init.copy()` (solver.py:85) and `U = self.solution.U`
@@ -155,7 +156,8 @@ int chs_step_n(chs_handle h, int64_t nsteps, int32_t flags, double* rows, int64_
                                 previous call (used to feed per-step host jitter noise while
                                 keeping the reference's carried hat_U, solver.py:206-211) */
 
-#define CHS_STEP_REDERIVE_HAT 2 /* recompute hat_U = dctn(U) on entry (the literal solver.py:159) even when the
+#define CHS_STEP_REDERIVE_HAT 2 /* (implies that the call's last step prepares no continuation either, like CHS_STEP_LAST_CALL)
+                                  recompute hat_U = dctn(U) on entry (the literal solver.py:159) even when the
                                   previous call left the loop's state on the device.  Without it a call with a
                                   fixed time step that follows a completed call (no new field, state or noise
                                   in between) continues that call's loop: hat_U is carried instead of being
