@@ -506,6 +506,7 @@ def test_fp32_n8192_adaptive_steps_vs_oracle_seeded_at_step_499(gpu):
     eng = s._engine
     st = eng.get_state()
     st.computed_steps = 499
+    st.skip_check = 1          # (the energy rule indexes the record by step number, timedata.py:63: not with a seeded counter)
     eng.set_state(st)
     rows, rc = eng.step_n(steps)
     assert rc == 0 and rows.shape == (steps, 9)
@@ -513,6 +514,7 @@ def test_fp32_n8192_adaptive_steps_vs_oracle_seeded_at_step_499(gpu):
     o = orc.OracleSolver(orc.make_params(N, 10 ** 6, **kw))
     o.prepare()
     o.computed_steps = 499
+    o.skip_check = True
     o.solve_or_resume(steps)
     to = o.timedata.data()[1:]
     assert np.array_equal(rows[:, 0], to[:, 0]) and rows[0, 0] == 499 and rows[-1, 0] == 506
