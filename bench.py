@@ -406,7 +406,7 @@ def main():
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(f'{eng.engine}:{dom}:N{N}')
+                traffic = json.load(open(tf)).get(f'{eng.engine}:{dom}:N{N}' + (':f32' if esz == 4 else ''))
             except Exception:
                 traffic = None
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,

@@ -40,8 +40,6 @@ struct DevState {
   unsigned long long decided;
   int gate_timeout;
   int pad_;
-  // persistent column pass (k_col_pers): the launch whose deferred bookkeeping has been taken on by a workgroup
-  unsigned long long tail_claim;
 };
 
 // Read-only scalars, passed to kernels by value.
@@ -200,9 +198,6 @@ struct Engine {
   bool testGateWithhold = false;  // test hook (CHS_TEST_GATE_WITHHOLD=1 at chs_create): gated tails never publish
   bool preRider = false;      // the first step's time-step control rides in its k_col (deferred-tail mode)
   unsigned stepCount = 0;     // k_col<MODE_STEP> launches so far (tile walk direction alternates)
-  unsigned* dQueues = nullptr;  // persistent column pass: CHS_QUEUE_SETS sets of 8 per-XCD item counters
-  unsigned persLaunch = 0;      // ... launches so far (selects the counter set; never reset: the sets ahead are clean)
-  int numCU = 0;
   // jitter noise generated on the device: numpy's PCG64 stream continued from the host generator's state
   bool jitterPcg = false;
   unsigned long long pcgState[2] = {0, 0}, pcgInc[2] = {0, 0};  // {hi, lo}

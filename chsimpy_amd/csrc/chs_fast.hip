@@ -112,17 +112,6 @@ int chs_fast_init(Engine* E) {
   CHS_HIP(hipMalloc(&E->partSet[1][1], sizeof(double) * (size_t)(E->nBands > E->N ? E->nBands : E->N)));
   CHS_HIP(hipMalloc(&E->partSet[1][2], sizeof(double) * (size_t)E->nPartE2));
   CHS_HIP(hipMalloc(&E->partSet[1][3], sizeof(double) * 8));
-  // item queues of the persistent column pass (chs_fast_pers.h); CHS_COL_PERS=0 keeps the one-workgroup-per-item kernel
-  {
-    const char* e = getenv("CHS_COL_PERS");
-    if (!(e && e[0] == '0')) {
-      CHS_HIP(hipMalloc(&E->dQueues, sizeof(unsigned) * 8 * CHS_QUEUE_SETS));
-      CHS_HIP(hipMemset(E->dQueues, 0, sizeof(unsigned) * 8 * CHS_QUEUE_SETS));
-    }
-    hipDeviceProp_t prop;
-    CHS_HIP(hipGetDeviceProperties(&prop, E->hc.device));
-    E->numCU = prop.multiProcessorCount;
-  }
   return chs_fast_rearm(E);
 }
 
@@ -155,8 +144,6 @@ void chs_fast_free(Engine* E) {
   }
   if (E->dPartColRows) hipFree(E->dPartColRows);
   E->dPartColRows = nullptr;
-  if (E->dQueues) hipFree(E->dQueues);
-  E->dQueues = nullptr;
   if (E->dPartE2) hipFree(E->dPartE2);
   if (E->dPartRa) hipFree(E->dPartRa);
   E->dPartRa = nullptr;

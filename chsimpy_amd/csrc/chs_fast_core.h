@@ -461,24 +461,8 @@ __device__ __forceinline__ void mv_last(typename C::V* z, typename C::T* scr, in
     }                                                                                  \
   } while (0)
 
-// The pass-0 twiddles omega_M^(m k), k = 1..R0-1, of butterfly m.  POW: only the k = 1 entries are at hand
-// (tw0[m], e.g. in LDS where the whole table does not fit): the others are its powers, w_k = w_(k/2) w_(k - k/2)
-// -- at most three products deep, a few ulp.
-template <class C, bool POW>
-__device__ __forceinline__ void tw0_load(const typename C::T* tw0, int m, typename C::V* w /* [R0], w[0] unused */) {
-  using T = typename C::T;
-  if constexpr (!POW) {
-#pragma unroll
-    for (int k = 1; k < C::R0; ++k) w[k] = ldc<T>(tw0, (k - 1) * C::L1 + m);
-  } else {
-    w[1] = ldc<T>(tw0, m);
-#pragma unroll
-    for (int k = 2; k < C::R0; ++k) w[k] = cx_mul(w[k / 2], w[k - k / 2]);
-  }
-}
-
 // Forward: pass-0 operands in -> last-pass outputs Z out (index ((q*2+b)*RL + k)).
-template <class C, bool TW0POW = false>
+template <class C>
 __device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr, const FTables<typename C::T>& tb, int l) {
   using T = typename C::T;
   using V = typename C::V;
@@ -491,10 +475,8 @@ __device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr,
       const int m = b ? (C::L1 - 1 - m1) : m1;
       V* r = z + (q * 2 + b) * C::R0;
       Dft<V, C::R0, false>::run(r);
-      V w[C::R0];
-      tw0_load<C, TW0POW>(tb.tw0, m, w);
 #pragma unroll
-      for (int k = 1; k < C::R0; ++k) r[k] = cx_mul(r[k], w[k]);
+      for (int k = 1; k < C::R0; ++k) r[k] = cx_mul(r[k], ldc<T>(tb.tw0, (k - 1) * C::L1 + m));
     }
   }
   if constexpr (C::RA > 1) {
@@ -516,7 +498,7 @@ __device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr,
 }
 
 // Inverse (exact transpose): last-pass output gradients in -> pass-0 operands out.
-template <class C, bool TW0POW = false>
+template <class C>
 __device__ __forceinline__ void inv_passes(typename C::V* z, typename C::T* scr, const FTables<typename C::T>& tb, int l) {
   using T = typename C::T;
   using V = typename C::V;
@@ -543,10 +525,8 @@ __device__ __forceinline__ void inv_passes(typename C::V* z, typename C::T* scr,
     for (int b = 0; b < 2; ++b) {
       const int m = b ? (C::L1 - 1 - m1) : m1;
       V* r = z + (q * 2 + b) * C::R0;
-      V w[C::R0];
-      tw0_load<C, TW0POW>(tb.tw0, m, w);
 #pragma unroll
-      for (int k = 1; k < C::R0; ++k) r[k] = cx_mulc(r[k], w[k]);
+      for (int k = 1; k < C::R0; ++k) r[k] = cx_mulc(r[k], ldc<T>(tb.tw0, (k - 1) * C::L1 + m));
       Dft<V, C::R0, true>::run(r);
     }
   }

@@ -58,10 +58,6 @@ using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, CHS_PAD1, CH
 #define CHS_F4096C_TW_LDS 1
 #endif
 template <> struct ColTwLds<F4096C> { static constexpr bool value = (CHS_F4096C_TW_LDS != 0); };
-#ifndef CHS_F4096C_PERS
-#define CHS_F4096C_PERS 1
-#endif
-template <> struct ColPers<F4096C> { static constexpr bool value = (CHS_F4096C_PERS != 0); };
 
 // fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
 // two rows or two of a tile's four columns per 512-thread workgroup)

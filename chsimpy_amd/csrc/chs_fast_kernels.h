@@ -588,10 +588,6 @@ constexpr int col_tw_elems() {
 template <class C>
 struct ColTwLds { static constexpr bool value = true; };
 
-// ... and whether a configuration runs the column pass of a timestep as the persistent kernel of chs_fast_pers.h
-template <class C>
-struct ColPers { static constexpr bool value = false; };
-
 template <class C>
 constexpr int col_lds_elems() {
   return (C::C * C::SCR > ColStage<C>::ELEMS) ? C::C * C::SCR : ColStage<C>::ELEMS;
@@ -899,8 +895,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   }
 }
 
-#include "chs_fast_pers.h"
-
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -937,8 +931,6 @@ struct Launch {
   // staging / exchange scratch + the pass twiddles (k_col<MODE_STEP>)
   static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (ColTwLds<CC>::value ? (size_t)col_tw_elems<CC>() : 0)) * sizeof(T);
   static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
-  // the persistent column pass with LDS-DMA prefetch (chs_fast_pers.h): fp64, whole-wavefront groups, 16-byte row pieces
-  static constexpr bool PERS = (sizeof(T) == 8) && PersStage<CC>::OK && ColPers<CC>::value;
 
   template <class K>
   static int set_lds(K kernel, size_t bytes) {
@@ -960,9 +952,6 @@ struct Launch {
     E->adaptOk = ADAPT_OK;
     E->fusedAdapt = ADAPT_OK && getenv("CHS_ADAPT_SWEEP") == nullptr;  // CHS_ADAPT_SWEEP=1: keep the separate sweep of U
     if ((rc = set_lds(k_col<CC, MODE_STEP>, col_lds))) return rc;
-    if constexpr (PERS) {
-      if ((rc = set_lds(k_col_pers<CC>, PersStage<CC>::LDS_BYTES))) return rc;
-    }
     if ((rc = set_lds(k_col<CC, MODE_FWD_NATIVE>, col_lds))) return rc;
     if ((rc = set_lds(k_col<CC, MODE_FWD_NATURAL>, col_lds))) return rc;
     if ((rc = set_lds(k_col<CC, MODE_INV_NATURAL>, col_lds))) return rc;
@@ -1029,19 +1018,6 @@ struct Launch {
         E->preRider = false;
         ta.reverse = (CHS_COL_ZIGZAG && (E->stepCount & 1)) ? 1 : 0;
         ++E->stepCount;
-        if constexpr (PERS) {
-          if (E->dQueues != nullptr && nat == nullptr) {
-            // two workgroups per CU for the whole launch (a multiple of the 8 queues), never more than there are items
-            int nwg = 2 * (E->numCU > 0 ? E->numCU : 256);
-            nwg -= nwg % 8;
-            if (nwg > grid) nwg = grid;
-            ta.claim_seq = (unsigned long long)E->persLaunch + 1;
-            k_col_pers<CC><<<nwg, CC::THREADS, PersStage<CC>::LDS_BYTES, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda,
-                                                                                  E->dSinSq, E->dState, E->dPartE2, ta, E->dQueues, E->persLaunch);
-            ++E->persLaunch;
-            break;
-          }
-        }
         k_col<CC, MODE_STEP><<<g, CC::THREADS, col_lds, E->stream>>>((const T*)tin, (T*)tout, (T*)hat, (T*)nat, tb, E->dLambda, E->dSinSq, E->dState, E->dPartE2, ta);
         break;
       }

@@ -79,7 +79,6 @@ struct TailArgs {
   unsigned long long seq = 0;     // ... under this sequence number (DevState::decided)
   int gate_spins = 1 << 20;       // polls (s_sleep 16 between them, ~1 us each) before a waiting workgroup gives up
   int withhold = 0;               // test hook (CHS_TEST_GATE_WITHHOLD): the decision is never published
-  unsigned long long claim_seq = 0;  // persistent column pass: this launch's ticket for the deferred bookkeeping
   int pre_only = 0;  // first step of a call: no record yet, only the time-step control of the coming step
   int reverse = 0;  // (k_col rider, not a tail input) walk the column tiles in descending order this step
   DevConsts dc;

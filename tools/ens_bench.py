@@ -2,7 +2,8 @@ import sys, time, os
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import chsimpy_amd
 from chsimpy_amd import experiment as ex
-for conc in (1, 2, 3, 4):
+concs = [int(x) for x in sys.argv[1:]] or [1, 2, 3, 4]
+for conc in concs:
     p = chsimpy_amd.Parameters()
     p.N, p.ntmax, p.full_sim, p.kappa_tilde, p.file_id = 2048, 400, True, 0.0002989112919661156, '/tmp/ens'
     ep = ex.ExperimentParams(); ep.runs = 8

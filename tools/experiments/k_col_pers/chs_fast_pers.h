@@ -158,8 +158,12 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col_pers(const typename 
   double lam1 = st->lam1, lam2 = st->lam2;  // (gated launches read them again behind the gate)
   bool gate_open = !(ta.enabled && ta.gate);
 
+  // (diagnostic build -DCHS_STAMPS: phase stamps of every workgroup's SECOND item -- steady state -- into buffer 2)
+  [[maybe_unused]] int it_no = 0;
+#define PSTAMP(I) do { if (it_no == 1) STAMP(2, I); } while (0)
 #pragma unroll 1
   while (item < IPX) {
+    PSTAMP(0);
     // (laundered: whatever is derived from the lane indices is recomputed in every iteration instead of being
     // hoisted out of the loop and kept in registers -- or spilled -- across its whole body)
     const int l = launder(l0), sub = launder(sub0);
@@ -178,15 +182,20 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col_pers(const typename 
     // round 0 (issued an item ago, or just above for the first item): every operation but my NDMA youngest is done
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PS::NDMA) : "memory");
     __syncthreads();
+    PSTAMP(1);
     V z[C::E];
     read_quads(A, 0, z);
+    PSTAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PSTAMP(3);
     read_quads(S, 1, z);
     __syncthreads();   // A and S are free again
+    PSTAMP(4);
     // the first half of the next item's tile streams into A from here on, under the passes
     if (next < IPX) dma_round(next, 0, A);
     fwd_passes<C, true>(z, scr, tbp, launder(l));
+    PSTAMP(5);
     if (!gate_open) {
       if (gate_wait(st, ta.seq, ta.gate_spins, red, lam1, lam2)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no DMA in flight towards an LDS allocation that is given back)
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col_pers(const typename 
       gate_open = true;
     }
     if (threadIdx.x == 0) box[0] = draw();   // the item after next; read behind the barriers of the stage-out
+    PSTAMP(6);
     // ---- recombination / spectral stage / adjoint recombination, in place per slot (as k_col<MODE_STEP>)
     struct Fetched { double2 ls[4]; V h01, h23; };
     double e2 = 0.0;
@@ -231,7 +241,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col_pers(const typename 
         }
       });
     if (l == 0 && kc == 0) st->meanU = (double)h00 / (double)C::N;  // ortho DC term = sum(U)/N (solver.py:223)
+    PSTAMP(7);
     inv_passes<C, true>(z, scr, tbp, launder(l));
+    PSTAMP(8);
     // ---- stage out through S: quads -> tile rows (k_col's padded image)
     T* tile = Tout + (size_t)ct * C::N * C::CT;
 #pragma unroll
@@ -262,14 +274,18 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col_pers(const typename 
         *reinterpret_cast<double2*>(dst) = make_double2(a, b);
       }
     }
+    PSTAMP(9);
     // the tile's share of the spectral gradient sum (one barrier: S is free behind it)
     const double acc1[1] = {e2};
     double tot1[1];
     block_sum_store<1, C::THREADS / 64>(acc1, red, tot1);
     if (threadIdx.x == 0) partE2[bid] = tot1[0];
+    PSTAMP(10);
     item = next;
     next = box[0];
+    ++it_no;
   }
+#undef PSTAMP
   // ---- the deferred bookkeeping (nobody waits for it): the first workgroup of the launch to run out of items does
   // it while the others finish theirs -- it fills the gap the end of the launch leaves anyway
   if (ta.enabled && !ta.gate) {

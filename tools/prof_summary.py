@@ -45,13 +45,14 @@ def main(d):
             print(f"    {c:28s} {sum(v) / len(v):16.1f}   (n={len(v)})")
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and not (len(sys.argv) > 2 and sys.argv[2] == '--traffic'):
     main(sys.argv[1])
 
 
-def traffic(d, out_json, N=4096):
-    """profiles/traffic.json from a session: HBM-side bytes per launch of the two per-step kernels, from the
-    FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md (HBM section) prescribes."""
+def traffic(d, out_json, N=4096, suffix=''):
+    """Adds to profiles/traffic.json from a session: L2<->fabric bytes per launch of the two per-step kernels, from the
+    FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md (HBM section) prescribes.  Keys
+    `fast:<kernel>:N<N><suffix>` (suffix ':f32' for the fp32 engine) -- what bench.py looks up for `roofline.traffic`."""
     import json
     agg = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(d, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
@@ -63,15 +64,20 @@ def traffic(d, out_json, N=4096):
             "all dispatches of the kernel template (incl. the lighter entry-transform / last-step variants). These are "
             "L2<->fabric bytes: requests served by the 256 MB Infinity Cache are included, so this is an upper bound of the HBM traffic")
     out = {}
+    if os.path.exists(out_json):
+        try:
+            out = json.load(open(out_json))
+        except Exception:
+            out = {}
     for kern, key in (('k_col', 'k_col'), ('k_row_inv', 'k_row_inv (fused)')):
         if kern in agg and agg[kern]['FETCH_SIZE'] and agg[kern]['WRITE_SIZE']:
             fk = sum(agg[kern]['FETCH_SIZE']) / len(agg[kern]['FETCH_SIZE'])
             wk = sum(agg[kern]['WRITE_SIZE']) / len(agg[kern]['WRITE_SIZE'])
-            out[f'fast:{key}:N{N}'] = {'hbm_bytes_per_launch': int(2 * fk * 1024 + wk * 1024), 'FETCH_SIZE_KB': round(fk, 1),
-                                       'WRITE_SIZE_KB': round(wk, 1), 'note': note}
+            out[f'fast:{key}:N{N}{suffix}'] = {'hbm_bytes_per_launch': int(2 * fk * 1024 + wk * 1024), 'FETCH_SIZE_KB': round(fk, 1),
+                                               'WRITE_SIZE_KB': round(wk, 1), 'session': os.path.basename(d.rstrip('/')), 'note': note}
     json.dump(out, open(out_json, 'w'), indent=1)
-    print(json.dumps(out, indent=1))
+    print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in out.items()}, indent=1))
 
 
 if __name__ == '__main__' and len(sys.argv) > 3 and sys.argv[2] == '--traffic':
-    traffic(sys.argv[1], sys.argv[3])
+    traffic(sys.argv[1], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 4096, sys.argv[5] if len(sys.argv) > 5 else '')
