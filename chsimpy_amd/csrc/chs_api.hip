@@ -142,7 +142,7 @@ bool pool_enabled() { const char* e = getenv("CHS_ENGINE_POOL"); return !(e && e
 // hat_U of the small grids' stop-rule runs, the adaptive step's partial rows])
 size_t engine_bytes(const Engine* E) {
   const size_t nb = (size_t)E->N * E->N * E->esz;
-  return nb * (5 + (E->dHat2 ? 1 : 0) + (E->dNoise ? 1 : 0)) + (E->dPartColRows ? (size_t)E->nRowBlocks * E->N * 8 : 0);
+  return nb * (5 + (E->dHat2 ? 1 : 0) + (E->dNoise ? 1 : 0)) + (E->dPartColRows ? (size_t)E->nRowBlocks * E->N * E->esz : 0);
 }
 }
 // Frees every parked engine (the process's only library-owned state besides the handles): for a caller that

@@ -203,7 +203,7 @@ struct Engine {
   unsigned long long pcgState[2] = {0, 0}, pcgInc[2] = {0, 0};  // {hi, lo}
   bool adaptOk = false;       // the configuration has the fused adaptive row kernel
   bool fusedAdapt = false;    // the fused row kernel adds up the adaptive-step integrand itself
-  double* dPartColRows = nullptr;  // [nRowBlocks][N] partial column sums of that integrand
+  void* dPartColRows = nullptr;    // [nRowBlocks][N] partial column sums of that integrand, in the engine's element type
   double* dColSlices = nullptr;    // [CS_SLICES][N] first stage of their reduction (chs_launch_colmin_rows)
   bool storeU = true;         // the fused row kernel writes U on intermediate steps (chs_fast_step)
   int tailSet = 0;            // ... on this partial set

@@ -120,7 +120,7 @@ int chs_fast_init(Engine* E) {
 int chs_fast_rearm(Engine* E) {
   E->fusedAdapt = E->adaptOk && getenv("CHS_ADAPT_SWEEP") == nullptr;
   if (E->dc.adaptive_time && E->fusedAdapt && !E->dPartColRows)
-    CHS_HIP(hipMalloc(&E->dPartColRows, sizeof(double) * (size_t)E->nRowBlocks * E->N));
+    CHS_HIP(hipMalloc(&E->dPartColRows, E->esz * (size_t)E->nRowBlocks * E->N));
   if (E->partSet[0][0]) {
     E->dPartDiag = E->partSet[0][0]; E->dPartMu = E->partSet[0][1];
     E->dPartE2 = E->partSet[0][2]; E->dPartRa = E->partSet[0][3];

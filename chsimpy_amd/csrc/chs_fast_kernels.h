@@ -341,7 +341,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
                                                     DevConsts dc, const DevState* __restrict__ st,
                                                     double* __restrict__ partDiag, double* __restrict__ partMu,
                                                     double* __restrict__ partRa, int store_u,
-                                                    double* __restrict__ partColRows = nullptr) {
+                                                    typename C::T* __restrict__ partColRows = nullptr) {
   using T = typename C::T;
   __shared__ double red[64];
   if (st->halt) return;
@@ -471,17 +471,20 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     // sums of delt_max/sqrt(1 + alpha*mu^2) are needed.  mu of the next step is in the registers
     // right now: every workgroup adds up its rows per column (through the idle exchange scratch) and
     // writes one partial row; k_colsum_slices / k_colmin_slices add them up and take the minimum.  No sweep of U.
-    // NH passes over the columns when a row of doubles does not fit the scratch (fp32 transforms)
+    // The partial sums of a workgroup's few rows travel in the engine's element type (fp32 engine: a sum of two to
+    // four fp32 terms per column, added up in fp64 by the reduction kernels -- half the bytes of the N/2 partial rows).
+    // NH passes over the columns when a row of them does not fit the scratch
     constexpr int LDSB = C::C * C::SCR * (int)sizeof(T);
-    constexpr int NH = (C::C == 1 || C::N * 8 <= LDSB) ? 1 : 2;
+    constexpr int NH = (C::C == 1 || C::N * (int)sizeof(T) <= LDSB) ? 1 : 2;
     constexpr int JH = (C::R0 / 2) / NH;  // quads j*L1 .. (j+1)*L1 cover a quarter (R0 = 8) of the columns each
-    static_assert(!ADAPT || (FUSE && C::C <= 4 && (C::C == 1 || C::N * 8 / NH <= LDSB) && (C::R0 / 2) % NH == 0),
+    static_assert(!ADAPT || (FUSE && C::C <= 4 && (C::C == 1 || C::N * (int)sizeof(T) / NH <= LDSB) && (C::R0 / 2) % NH == 0),
                   "partial column sums need the scratch");
     const long long cs = st->computed_steps + 1;  // the record of this step has not advanced it yet
     if (cs > 500 && (cs % 2) == 0) {              // (uniform) cf. k_mu's want_col
       const int lg = launder(l);
-      double* prow = partColRows + (size_t)blockIdx.x * C::N;
-      double* gl = reinterpret_cast<double*>(chs_dyn_lds);
+      T* prow = partColRows + (size_t)blockIdx.x * C::N;
+      T* gl = reinterpret_cast<T*>(chs_dyn_lds);
+      const T dmax = (T)dc.delt_max;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
 #pragma unroll
@@ -499,8 +502,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
                 const int o1 = c1 - h * (C::N / NH), o2 = c2 - h * (C::N / NH);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  double g1 = chs_dt_integrand((double)q1[e], dc.delt_max);
-                  double g2 = chs_dt_integrand((double)q2[e], dc.delt_max);
+                  T g1 = chs_dt_integrand_fast(q1[e], dmax);
+                  T g2 = chs_dt_integrand_fast(q2[e], dmax);
                   if (s < C::C - 1) { g1 += gl[o1 + e]; g2 += gl[o2 + e]; }
                   if (s > 0) { gl[o1 + e] = g1; gl[o2 + e] = g2; }
                   else { prow[c1 + e] = g1; prow[c2 + e] = g2; }
@@ -927,7 +930,7 @@ struct Launch {
   using T = typename C::T;
   static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16;
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
-  static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(double) / 2 <= row_lds) && (C::R0 % 4 == 0);
+  static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(T) / 2 <= row_lds) && (C::R0 % 4 == 0);
   // staging / exchange scratch + the pass twiddles (k_col<MODE_STEP>)
   static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (ColTwLds<CC>::value ? (size_t)col_tw_elems<CC>() : 0)) * sizeof(T);
   static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
@@ -990,7 +993,7 @@ struct Launch {
     else {
       if constexpr (ADAPT_OK)
         k_row_inv<C, true, true, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)t2, (T*)u, (T*)t1, tb, E->dc, E->dState,
-                                                                          E->dPartDiag, E->dPartMu, E->dPartRa, E->storeU ? 1 : 0, E->dPartColRows);
+                                                                          E->dPartDiag, E->dPartMu, E->dPartRa, E->storeU ? 1 : 0, (T*)E->dPartColRows);
       else { chs_set_error("fused adaptive row kernel is not built for this configuration"); return CHS_EINVAL; }
     }
     CHS_HIP(hipGetLastError());

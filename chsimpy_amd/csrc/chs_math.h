@@ -247,6 +247,22 @@ __device__ __forceinline__ double chs_dt_integrand(double mu, double delt_max) {
   return delt_max / sqrt(1.0 + a);
 }
 
+// The same integrand where it is evaluated for every grid point of every second step (the fused row kernel): a
+// reciprocal square root instead of a square root and a division.  fp64: v_rsq_f64 refined by two Newton steps
+// (~2 ulp; the column sums agree with the oracle's to 1e-15); fp32 engine: the hardware's v_rsq_f32 (1 ulp), in the
+// precision of its operand mu.
+__device__ __forceinline__ double chs_dt_integrand_fast(double mu, double delt_max) {
+  const double a = __builtin_fma(62.5 * mu, mu, 1.0);
+  const double h = 0.5 * a;
+  double y = __builtin_amdgcn_rsq(a);
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  return delt_max * y;
+}
+__device__ __forceinline__ float chs_dt_integrand_fast(float mu, float delt_max) {
+  return delt_max * __builtin_amdgcn_rsqf(__builtin_fmaf(62.5f * mu, mu, 1.0f));
+}
+
 // Semi-implicit spectral update, chsimpy/solver.py:201-206 with the grids of
 // chsimpy/utils.py:41-48 formed on the fly:
 //   leig = lam_i + lam_j; CHeig = 1 + lam2*leig*leig; Seig = lam1*leig

@@ -493,7 +493,7 @@ int chs_launch_mu(Engine* E) {
   return CHS_OK;
 }
 
-static int launch_colmin(Engine* E, const double* rows, int nRows, int cs_offset);
+static int launch_colmin(Engine* E, const void* rows, bool rows_f32, int nRows, int cs_offset);
 
 int chs_launch_mu_colsums(Engine* E, int cs_offset) {
   chs_slot_begin(E, SLOT_MISC);
@@ -502,7 +502,7 @@ int chs_launch_mu_colsums(Engine* E, int cs_offset) {
                                                             E->dPartMuAux, E->dPartCol, 1, cs_offset)),
     (k_mu<float><<<E->nBands, PW_THREADS, 0, E->stream>>>((const float*)E->dU, (float*)E->dMU, E->dc, E->dState,
                                                            E->dPartMuAux, E->dPartCol, 1, cs_offset)));
-  const int rcm = launch_colmin(E, E->dPartCol, E->nBands, cs_offset);
+  const int rcm = launch_colmin(E, E->dPartCol, false, E->nBands, cs_offset);
   chs_slot_end(E, SLOT_MISC);
   if (rcm) return rcm;
   CHS_HIP(hipGetLastError());
@@ -518,7 +518,8 @@ int chs_launch_mu_colsums(Engine* E, int cs_offset) {
 #define CS_COLS 64
 #define CS_SLICES 32
 #define CS_UN 8
-__global__ __launch_bounds__(PW_THREADS) void k_colsum_slices(const double* __restrict__ partRows, int nRows, int N,
+template <typename PT>
+__global__ __launch_bounds__(PW_THREADS) void k_colsum_slices(const PT* __restrict__ partRows, int nRows, int N,
                                                               const DevState* __restrict__ st, int adaptive,
                                                               double* __restrict__ slices, int cs_offset) {
   __shared__ double acc[PW_THREADS];
@@ -532,13 +533,13 @@ __global__ __launch_bounds__(PW_THREADS) void k_colsum_slices(const double* __re
   const int r0 = blockIdx.y * per, r1 = min(r0 + per, nRows);
   double s = 0.0;
   if (c < N) {
-    const double* col = partRows + c;
+    const PT* col = partRows + c;
     for (int rb = r0 + w; rb < r1; rb += NWV * CS_UN) {
-      double x[CS_UN];
+      PT x[CS_UN];
 #pragma unroll
       for (int u = 0; u < CS_UN; ++u) { const int r = rb + u * NWV; x[u] = col[(size_t)(r < r1 ? r : r0) * N]; }
 #pragma unroll
-      for (int u = 0; u < CS_UN; ++u) s += (rb + u * NWV < r1) ? x[u] : 0.0;
+      for (int u = 0; u < CS_UN; ++u) s += (rb + u * NWV < r1) ? (double)x[u] : 0.0;
     }
   }
   acc[threadIdx.x] = s;
@@ -571,11 +572,14 @@ __global__ __launch_bounds__(PW_THREADS) void k_colmin_slices(const double* __re
   if (threadIdx.x == 0) partColMin[blockIdx.x] = m;
 }
 
-// partColMin[0 .. nColMinBlocks) <- block minima of the column sums of rows[nRows][N]
-static int launch_colmin(Engine* E, const double* rows, int nRows, int cs_offset) {
+// partColMin[0 .. nColMinBlocks) <- block minima of the column sums of rows[nRows][N] (doubles, or floats: rows_f32)
+static int launch_colmin(Engine* E, const void* rows, bool rows_f32, int nRows, int cs_offset) {
   if (!E->dColSlices) CHS_HIP(hipMalloc(&E->dColSlices, sizeof(double) * (size_t)CS_SLICES * E->N));
   const dim3 g1((E->N + CS_COLS - 1) / CS_COLS, CS_SLICES);
-  k_colsum_slices<<<g1, PW_THREADS, 0, E->stream>>>(rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
+  if (rows_f32)
+    k_colsum_slices<float><<<g1, PW_THREADS, 0, E->stream>>>((const float*)rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
+  else
+    k_colsum_slices<double><<<g1, PW_THREADS, 0, E->stream>>>((const double*)rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
   k_colmin_slices<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dColSlices, E->N, E->dState, E->dc.adaptive_time,
                                                                   E->dPartColMin, cs_offset);
   E->nColMinCur = E->nColMinBlocks;
@@ -584,7 +588,7 @@ static int launch_colmin(Engine* E, const double* rows, int nRows, int cs_offset
 
 int chs_launch_colmin_rows(Engine* E, int cs_offset) {
   chs_slot_begin(E, SLOT_MISC);
-  const int rc = launch_colmin(E, E->dPartColRows, E->nRowBlocks, cs_offset);
+  const int rc = launch_colmin(E, E->dPartColRows, E->dtype == CHS_F32, E->nRowBlocks, cs_offset);
   chs_slot_end(E, SLOT_MISC);
   if (rc) return rc;
   CHS_HIP(hipGetLastError());
@@ -594,7 +598,7 @@ int chs_launch_colmin_rows(Engine* E, int cs_offset) {
 int chs_launch_pre(Engine* E) {
   chs_slot_begin(E, SLOT_PRE);
   if (E->dc.adaptive_time && E->engine == CHS_ENGINE_DIRECT) {
-    const int rcm = launch_colmin(E, E->dPartCol, E->nBands, 0);
+    const int rcm = launch_colmin(E, E->dPartCol, false, E->nBands, 0);
     if (rcm) { chs_slot_end(E, SLOT_PRE); return rcm; }
   }
   k_pre<<<1, PW_THREADS, 0, E->stream>>>(E->dc, E->dState, E->dPartMu, E->nPartMu, E->dPartColMin,

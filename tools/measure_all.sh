@@ -6,7 +6,8 @@ o=gpurun_out
 mkdir -p $o
 run() { name=$1; shift; timeout -k 10 400 python bench.py "$@" > $o/${tag}_$name.json 2> $o/${tag}_$name.err || echo "$name failed"; }
 run bench                                   # headline: N=4096 fp64, 300 + 5000 steps, with the CPU baseline
-run bench_driver --steps 20 --warmup 5 --no-cpu-baseline   # the driver's invocation
+run bench_driver --steps 20 --warmup 5 --no-cpu-baseline   # the driver's invocation (literal solve_or_resume call)
+run bench_driver_continue --steps 20 --warmup 5 --no-cpu-baseline --continue-loop
 run bench_energy_stop --energy-stop --no-cpu-baseline
 run bench_n2048 --grid 2048 --no-cpu-baseline
 run bench_n1024 --grid 1024 --no-cpu-baseline

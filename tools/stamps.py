@@ -13,6 +13,7 @@ NST = 12
 p = chsimpy_amd.Parameters()
 NN = int(os.environ.get('CHS_STAMP_N', '4096'))
 p.N, p.ntmax, p.full_sim, p.kappa_tilde = NN, 10 ** 9, os.environ.get('CHS_STAMP_FULLSIM', '1') == '1', 0.0002989112919661156
+p.dtype = os.environ.get('CHS_STAMP_DTYPE', 'float64')
 s = chsimpy_amd.Solver(p)
 s.prepare()
 s.solve_or_resume(6)
