@@ -15,10 +15,14 @@
 // = the 8 full-array transfers per timestep of SURVEY.md section 8(d).
 //
 // HBM layouts.  U is row-major (it is the boundary's array).  T1/T2 are "column-tile
-// major": element (r, k) lives at ((k / C) * N + r) * C + (k % C) with C = 256/G columns
-// per tile, so a column tile is one contiguous slab (k_col streams it with 16-byte
-// coalesced accesses through an LDS stage) while the row kernels touch it in C*8-byte
-// pieces, four consecutive rows (one workgroup) completing each 128-byte line.
+// major": element (r, c) of PHYSICAL column c lives at ((c / CT) * N + r) * CT + (c % CT) with CT
+// columns per tile, so a column tile is one contiguous slab (k_col streams it with 16-byte
+// coalesced accesses through an LDS stage) while the row kernels touch it in CT*sizeof(T)-byte
+// pieces, consecutive rows completing each 128-byte line.
+// fp64: physical column = coefficient index.  fp32 (FCfg::SLOT): the physical columns are in SLOT ORDER: column
+// 4 s + t holds coefficient t of recombination slot s -- the four coefficients {kk, N-kk, M-kk, M+kk} a lane of a
+// row kernel produces (or consumes) together are one contiguous 16-byte piece, ONE access instead of four scattered
+// 4-byte ones (row_access; col_coef maps a physical column back to its coefficient for k_col's spectral constants).
 // hat_U lives in k_col's native order: column kc at kc*N, inside it the lane's positions in PAIRS -- positions
 // (2j, 2j+1) of lane l are the two components of the value pair number j*G + l (hat_pair_index): a recombination
 // slot's four coefficients are two 16-byte (fp64) / 8-byte (fp32) accesses per lane, contiguous across the
@@ -72,12 +76,61 @@ extern "C" int chs_debug_stamps(int which, unsigned long long* out, int n) {
 
 enum { MODE_STEP = 0, MODE_FWD_NATIVE = 1, MODE_FWD_NATURAL = 2, MODE_INV_NATURAL = 3, MODE_INV_NATIVE = 4 };
 
-// Element (r, k) of a tile-major array through a 32-bit BYTE offset from the (uniform) array base: the
-// access becomes `global_load/store v, voffset, s[base]` -- one or two integer instructions per address
-// instead of a 64-bit multiply-add chain.  N*N*sizeof(T) < 2^32 for every configuration (<= 512 MB).
+// Accesses to the tile-major arrays go through a 32-bit BYTE offset from the (uniform) array base:
+// `global_load/store v, voffset, s[base]` -- one or two integer instructions per address instead of a 64-bit
+// multiply-add chain.  N*N*sizeof(T) < 2^32 for every configuration (<= 512 MB).
+// Byte offset of the 4-element piece of recombination slot (q, k) of lane l in row r: the slot's number is
+// s = k * S2/2 + kap with kap = l + G q in [0, S2/2) (the special lane's own slot is s = 0: kap = 0, k = 0),
+// CT/4 slots share a tile.  pbase = (q*R2 + k)*4 is what recombine() hands its callbacks.
+template <class C>
+__device__ __forceinline__ unsigned slot_boff(unsigned r, int pbase, int l) {
+  static_assert(C::CT % 4 == 0, "a tile holds whole slots");
+  constexpr unsigned SPT = C::CT / 4;
+  const unsigned s = (unsigned)(((pbase / 4) % C::R2) * (C::S2 / 2) + C::G * ((pbase / 4) / C::R2)) + (unsigned)l;
+  return (((s / SPT) * C::N + r) * C::CT + (s % SPT) * 4) * (unsigned)sizeof(typename C::T);
+}
+// element (r, k) of a tile-major array in the natural column order
 template <class C>
 __device__ __forceinline__ unsigned tile_boff(unsigned r, unsigned k) {
   return (((k / C::CT) * C::N + r) * C::CT + (k % C::CT)) * (unsigned)sizeof(typename C::T);
+}
+// coefficient index held by physical column c (SLOT: the inverse of the slot order; Own::slot_kk / out_index)
+template <class C>
+__device__ __forceinline__ int col_coef(int c) {
+  if constexpr (!C::SLOT) return c;
+  constexpr int H = C::R2 / 2, HS = C::S2 / 2;
+  const int s = c >> 2, t = c & 3;
+  const int k = s / HS, kap = s % HS;
+  if (kap == 0 && k == 0) return t * (C::M / 2);                      // (X[0], X[M/2], X[M], X[3M/2])
+  const int kk = (kap == 0) ? ((k < H) ? C::S2 * k : HS + C::S2 * (k - H)) : kap + C::S2 * k;
+  return t == 0 ? kk : (t == 1 ? C::N - kk : (t == 2 ? C::M - kk : C::M + kk));
+}
+template <typename T>
+__device__ __forceinline__ const T* at_boff(const T* base, unsigned boff);
+template <typename T>
+__device__ __forceinline__ T* at_boff(T* base, unsigned boff);
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, T q[4]);
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const T q[4]);
+// the four coefficients y[t] <-> columns idx[t] of row r of a tile-major array: slot (pbase, l) of a row kernel
+template <class C>
+__device__ __forceinline__ void row_store(typename C::T* base, unsigned r, int pbase, int l, const int* idx, const typename C::T y[4]) {
+  if constexpr (C::SLOT) {
+    store4<typename C::T>(at_boff(base, slot_boff<C>(r, pbase, l)), y);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *at_boff(base, tile_boff<C>(r, idx[t])) = y[t];
+  }
+}
+template <class C>
+__device__ __forceinline__ void row_load(const typename C::T* base, unsigned r, int pbase, int l, const int* idx, typename C::T y[4]) {
+  if constexpr (C::SLOT) {
+    load4<typename C::T>(at_boff(base, slot_boff<C>(r, pbase, l)), y);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y[t] = *at_boff(base, tile_boff<C>(r, idx[t]));
+  }
 }
 template <typename T>
 __device__ __forceinline__ const T* at_boff(const T* base, unsigned boff) {
@@ -194,7 +247,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
   typename C::V z[C::E];
   double s2 = 0.0;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
-  const unsigned urow = (unsigned)row * C::N;  // (32-bit offsets from the uniform base, see tile_boff)
+  const unsigned urow = (unsigned)row * C::N;  // (32-bit offsets from the uniform base, see slot_boff)
 #pragma unroll
   for (int q = 0; q < C::NP0; ++q) {
     const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
@@ -233,11 +286,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
   }
   fwd_passes<C>(z, scr, tb, l);
   recombine<C, true, false, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
-                            [&](int, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
+                            [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
     if (live) {
       const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) *at_boff(T1, tile_boff<C>(row, idx[t])) = y[t];
+      row_store<C>(T1, row, pbase, l, idx, y);
     }
   }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (POINTWISE) {
@@ -312,11 +364,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
     T* dst = pass ? T1 : Ta;
     fwd_passes<C>(z, scr, tb, launder(l));
     recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
-                              [&](int, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
+                              [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
       if (live) {
         const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) *at_boff(dst, tile_boff<C>(launder(row), idx[t])) = y[t];
+        row_store<C>(dst, launder(row), pbase, launder(l), idx, y);
       }
     }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
     __builtin_amdgcn_sched_barrier(0);
@@ -361,10 +412,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   typename C::V z[C::E];
   if constexpr (DIAG && FUSE) STAMP(0, 0);
   recombine<C, false, true, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
-                            [&](int, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool, NoFetch) {
+                            [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool, NoFetch) {
     T y[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) y[t] = *at_boff(T2, tile_boff<C>(row, idx[t]));
+    row_load<C>(T2, row, pbase, l, idx, y);
     Ya = cx_make(y[0], y[1]); Yb = cx_make(y[2], y[3]);
   }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
@@ -525,11 +575,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     __builtin_amdgcn_sched_barrier(0);
     recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
                               [](int, const int*, Cx<T>&, Cx<T>&, bool, NoFetch) {},
-                              [&](int, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live) {
+                              [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live) {
       if (live) {
         const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) *at_boff(T1, tile_boff<C>(row, idx[t])) = y[t];
+        row_store<C>(T1, row, pbase, launder(l), idx, y);
       }
     });
   }
@@ -649,7 +698,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     // last (hat_U of its last tiles, still in the 256 MB Infinity Cache) is touched first
     if (ta.reverse) ct = C::N / C::CT - 1 - ct;
   }
-  const int kc = ct * C::CT + hh * C::C + sub;  // this group's column
+  const int kcp = ct * C::CT + hh * C::C + sub;  // this group's (physical) column of T and hat_U ...
+  const int kc = col_coef<C>(kcp);               // ... and the coefficient index it holds (slot order, slot_boff)
   T* scr = lds + (size_t)sub * C::SCR;
   typename C::V z[C::E];
   // MODE_STEP: the twiddles of the radix passes come from LDS (copied once per workgroup; visible
@@ -667,10 +717,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     tbp.twa = ltw + 2 * (C::R0 - 1) * C::L1;
     tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
   }
-  T* hcol = hat + (size_t)kc * C::N;
+  T* hcol = hat + (size_t)kcp * C::N;
   // MODE_STEP with a second hat_U buffer (`nat`, chs_fast_step): the updated coefficients go there and the ones
   // read stay what they were -- the state of the last completed step if the riding tail stops the run
-  T* hout = (MODE == MODE_STEP && nat != nullptr) ? nat + (size_t)kc * C::N : hcol;
+  T* hout = (MODE == MODE_STEP && nat != nullptr) ? nat + (size_t)kcp * C::N : hcol;
   // constants of the spectral stage, requested here: their latency disappears behind the stage-in
   // (loaded where they are used they cost every workgroup ~4 K cycles of waiting)
   double lam1 = st->lam1, lam2 = st->lam2;  // (gated launches read them again behind the gate)
