@@ -364,7 +364,7 @@ def main():
     dev_ms = eng.last_step_ms()
     # the other protocol, right behind the timed region (same clocks), for the record
     other_ms = None
-    if world == 1:
+    if world == 1 and not a.energy_stop:   # (with the stop rule armed the run must still be alive for the profile leg below)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         rows_o, rc_o = eng.step_n(a.steps, **(literal if a.continue_loop else carried))
