@@ -266,20 +266,6 @@ struct Own {
     k1 = special ? 0 : kap;
     k2 = special ? C::S2 / 2 : C::S2 - kap;
   }
-  // frequency kk of recombination slot k of pair q
-  static __device__ __forceinline__ int slot_kk(int l, int q, int k) {
-    const int kap = l + C::G * q;
-    if (kap == 0) return (k < C::R2 / 2) ? C::S2 * k : C::S2 / 2 + C::S2 * (k - C::R2 / 2);
-    return kap + C::S2 * k;
-  }
-  // output index of position (q, k, t), t = 0..3  <->  (kk, N-kk, M-kk, M+kk);
-  // the special lane's position k=0 holds (X[0], X[M/2], X[M], X[3M/2]).
-  static __device__ __forceinline__ int out_index(int l, int q, int k, int t) {
-    const int kap = l + C::G * q;
-    if (kap == 0 && k == 0) return t * (C::M / 2);
-    const int kk = slot_kk(l, q, k);
-    return t == 0 ? kk : (t == 1 ? C::N - kk : (t == 2 ? C::M - kk : C::M + kk));
-  }
 };
 
 template <typename T>
@@ -541,19 +527,11 @@ __device__ __forceinline__ void inv_passes(typename C::V* z, typename C::T* scr,
 // Recombination stage, in place on the last-pass registers.
 //   FWD: (A, Z) -> Ya = (y0, y1), Yb = (y2, y3): the four real coefficients of the slot (slot_fwd)
 //   f(pbase, idx, Ya, Yb, live, fetched): the caller consumes / replaces them.  pbase = (q*R2 + k)*4 is the
-//        compile-time position of the slot, idx[t] the coefficient index of y_t (Own::out_index), idx[4] the
+//        compile-time position of the slot, idx[t] the coefficient index of y_t, idx[4] the
 //        slot's entry in per-slot tables: kk, or M + 1 for the special lane's own slot (indices 0, M/2, M, 3M/2).
 //   ADJ: (Ya, Yb) -> (gA, gZ) written back over (A, Z) (slot_adj)
 // With FWD only the registers are left untouched; with ADJ only Ya, Yb come from f.
 // ===========================================================================
-// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
-template <int I0, int I1, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I0 < I1) {
-    f(std::integral_constant<int, I0>{});
-    static_for<I0 + 1, I1>(f);
-  }
-}
 #ifndef CHS_RSTAMP
 #define CHS_RSTAMP(I) do {} while (0)
 #define CHS_RSTAMP1(I) do {} while (0)

@@ -94,7 +94,7 @@ template <class C>
 __device__ __forceinline__ unsigned tile_boff(unsigned r, unsigned k) {
   return (((k / C::CT) * C::N + r) * C::CT + (k % C::CT)) * (unsigned)sizeof(typename C::T);
 }
-// coefficient index held by physical column c (SLOT: the inverse of the slot order; Own::slot_kk / out_index)
+// coefficient index held by physical column c (SLOT: the inverse of the slot order of slot_boff)
 template <class C>
 __device__ __forceinline__ int col_coef(int c) {
   if constexpr (!C::SLOT) return c;

@@ -83,10 +83,14 @@ def test_config1_n512_1000steps(gpu):
 
 
 @pytest.mark.parametrize("N,nt", [(1024, 100), (2048, 40), (4096, 12)])
-def test_large_grids_against_the_oracle(gpu, N, nt):
+def test_large_grids_against_the_oracle(gpu, N, nt, monkeypatch):
     """The larger fast-engine configurations step by step against the oracle itself, as far as the
     oracle's CPU time allows (about 0.1 us per grid point and step): every configuration has its own
-    workgroup shapes and radices, N=4096 is the headline size."""
+    workgroup shapes and radices, N=4096 is the headline size.  The call is issued in batches of 5 steps
+    (CHS_BATCH_STEPS; 1024 in production, which the oracle cannot reach at these sizes), so the window does
+    cross issue batches -- the device-state poll between them, the row ring, the alternating partial-sum sets."""
+    monkeypatch.setenv('CHS_BATCH_STEPS', '5')
+    monkeypatch.setenv('CHS_ENGINE_POOL', '0')     # (a new engine, so that it reads the batch size)
     p = make(N, nt, 'fast')
     compare_run(p, {})
 
