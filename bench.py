@@ -365,6 +365,8 @@ def main():
     # the other protocol, right behind the timed region (same clocks), for the record
     other_ms = None
     if world == 1 and not a.energy_stop:   # (with the stop rule armed the run must still be alive for the profile leg below)
+        if not a.continue_loop:
+            eng.step_n(a.steps)   # a completed call whose loop the continuing call can take up (a literal call leaves none)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         rows_o, rc_o = eng.step_n(a.steps, **(literal if a.continue_loop else carried))
