@@ -452,8 +452,24 @@ __device__ __forceinline__ void mv_last(typename C::V* z, typename C::T* scr, in
     }                                                                                  \
   } while (0)
 
+// The pass-0 twiddles omega_M^(m k), k = 1..R0-1, of butterfly m.  POW: only the k = 1 entries are at hand
+// (tw0[m], in LDS where the whole table does not fit beside two resident workgroups): the others are its powers,
+// w_k = w_(k/2) w_(k - k/2) -- at most four products deep for R0 = 16.
+template <class C, bool POW>
+__device__ __forceinline__ void tw0_load(const typename C::T* tw0, int m, typename C::V* w /* [R0], w[0] unused */) {
+  using T = typename C::T;
+  if constexpr (!POW) {
+#pragma unroll
+    for (int k = 1; k < C::R0; ++k) w[k] = ldc<T>(tw0, (k - 1) * C::L1 + m);
+  } else {
+    w[1] = ldc<T>(tw0, m);
+#pragma unroll
+    for (int k = 2; k < C::R0; ++k) w[k] = cx_mul(w[k / 2], w[k - k / 2]);
+  }
+}
+
 // Forward: pass-0 operands in -> last-pass outputs Z out (index ((q*2+b)*RL + k)).
-template <class C>
+template <class C, bool TW0POW = false>
 __device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr, const FTables<typename C::T>& tb, int l) {
   using T = typename C::T;
   using V = typename C::V;
@@ -466,8 +482,10 @@ __device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr,
       const int m = b ? (C::L1 - 1 - m1) : m1;
       V* r = z + (q * 2 + b) * C::R0;
       Dft<V, C::R0, false>::run(r);
+      V w[C::R0];
+      tw0_load<C, TW0POW>(tb.tw0, m, w);
 #pragma unroll
-      for (int k = 1; k < C::R0; ++k) r[k] = cx_mul(r[k], ldc<T>(tb.tw0, (k - 1) * C::L1 + m));
+      for (int k = 1; k < C::R0; ++k) r[k] = cx_mul(r[k], w[k]);
     }
   }
   if constexpr (C::RA > 1) {
@@ -489,7 +507,7 @@ __device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr,
 }
 
 // Inverse (exact transpose): last-pass output gradients in -> pass-0 operands out.
-template <class C>
+template <class C, bool TW0POW = false>
 __device__ __forceinline__ void inv_passes(typename C::V* z, typename C::T* scr, const FTables<typename C::T>& tb, int l) {
   using T = typename C::T;
   using V = typename C::V;
@@ -516,8 +534,10 @@ __device__ __forceinline__ void inv_passes(typename C::V* z, typename C::T* scr,
     for (int b = 0; b < 2; ++b) {
       const int m = b ? (C::L1 - 1 - m1) : m1;
       V* r = z + (q * 2 + b) * C::R0;
+      V w[C::R0];
+      tw0_load<C, TW0POW>(tb.tw0, m, w);
 #pragma unroll
-      for (int k = 1; k < C::R0; ++k) r[k] = cx_mulc(r[k], ldc<T>(tb.tw0, (k - 1) * C::L1 + m));
+      for (int k = 1; k < C::R0; ++k) r[k] = cx_mulc(r[k], w[k]);
       Dft<V, C::R0, true>::run(r);
     }
   }

@@ -2,36 +2,37 @@
 #if !defined(CHS_STAMPS) || defined(CHS_FAST_UNITY_INCLUDE)
 #include "chs_fast_kernels.h"
 
-// fp32 configurations (BASELINE.json configs[3]: N = 8192 fp32): 32 complex values per lane
-// occupy the same 64 VGPRs as 16 fp64 ones; reductions and the spectral update stay in fp64.
+// fp32 configurations (BASELINE.json configs[3]: N = 8192 fp32): a complex value is one packed register pair
+// (chs_cx.h), so 32 values per lane occupy the 64 VGPRs of 16 fp64 ones; reductions stay in fp64.
+//
+// N = 8192 fp32: two wavefronts per transform, 32 complex values per lane, THREE radix-16 passes (two exchanges
+// instead of the three of 8.8.8.8: the exchanges with their workgroup barriers, not the packed arithmetic, are what
+// the passes of this size cost -- profiles/r03_stamps_n8192_fp32.txt), 256-thread workgroups: two rows, or two of a
+// tile's eight columns.  k_col keeps only the k = 1 entries of the pass-0 twiddle table (and the middle-pass table)
+// in LDS and forms the other 14 as their powers: the whole table (30 KB) would cost the second workgroup of a CU.
+// Measured on one box (profiles/r03_ab_occupancy.txt): 256 lanes x 16 values, 8.8.8.8: k_col 385-405 us, 1512-1554
+// steps/s; this shape with all pass twiddles from L2 349 us, 1660; with the k = 1 entries in LDS 313 us, 1763; with the
+// whole table in LDS (one workgroup per CU) 475 us.  The rows take 252-254 us in either shape.
 #ifndef CHS_G8192_WPS
-#define CHS_G8192_WPS 4
+#define CHS_G8192_WPS 2
 #endif
 #ifndef CHS_G8192C_WPS
 #define CHS_G8192C_WPS 2
 #endif
-// N = 8192 fp32: four wavefronts per transform, 16 complex values per lane, four radix-8 passes
-#ifndef CHS_G8192_THREADS
-#define CHS_G8192_THREADS 512
-#endif
 #ifndef CHS_F32_CT
-#define CHS_F32_CT 8  // columns per tile of the fp32 T layout at N >= 4096: 32-byte row pieces as in fp64 (4: N=8192 23 % slower)
-#endif
-#ifndef CHS_G8192_G
-#define CHS_G8192_G 256     // lanes per transform: 256 = 16 complex values per lane, 128 = 32 (the shape of fp64 N=4096)
-#endif
-#ifndef CHS_G8192C_THREADS
-#define CHS_G8192C_THREADS 512
+#define CHS_F32_CT 8  // columns per tile of the fp32 T layout at N >= 2048: 32-byte row pieces as in fp64 (4: N=8192 23 % slower)
 #endif
 #ifndef CHS_G8192C_TW_LDS
-#define CHS_G8192C_TW_LDS 1
+#define CHS_G8192C_TW_LDS 2
 #endif
-using G8192 = FCfg<float, 8192, CHS_G8192_G, CHS_G8192_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT>;
-using G8192C = FCfg<float, 8192, CHS_G8192_G, CHS_G8192C_THREADS, 8, 8, 8, 8, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
-template <> struct ColTwLds<G8192C> { static constexpr bool value = (CHS_G8192C_TW_LDS != 0); };
+using G8192 = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT>;
+using G8192C = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
+template <> struct ColTwLds<G8192C> { static constexpr int value = CHS_G8192C_TW_LDS; };
 #ifndef CHS_G4096_THREADS
 #define CHS_G4096_THREADS 256
 #endif
+// N = 4096 fp32: the shape of fp64 N = 4096 (64 lanes x 32 values with 16.8.16, wave-local exchanges, measured equal in
+// k_col and 6 % slower in the rows)
 using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, CHS_F32_CT>;
 using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, CHS_F32_CT>;
 // fp32 below N = 4096: the shapes of the fp64 configurations (groups inside one wavefront)

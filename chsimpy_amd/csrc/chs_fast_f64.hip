@@ -57,7 +57,7 @@ using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, CHS_PAD1, CH
 #ifndef CHS_F4096C_TW_LDS
 #define CHS_F4096C_TW_LDS 1
 #endif
-template <> struct ColTwLds<F4096C> { static constexpr bool value = (CHS_F4096C_TW_LDS != 0); };
+template <> struct ColTwLds<F4096C> { static constexpr int value = CHS_F4096C_TW_LDS; };
 
 // fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
 // two rows or two of a tile's four columns per 512-thread workgroup)

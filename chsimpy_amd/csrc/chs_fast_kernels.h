@@ -629,16 +629,17 @@ struct ColStage {
   }
 };
 
-// elements of the pass twiddle tables tw0 | twa | twb (contiguous in the table buffer, build_tables)
+// k_col<MODE_STEP> keeps the pass twiddles in LDS (value 1) unless a configuration says otherwise: 0 = all from L2,
+// 2 = the middle-pass tables and only the k = 1 entries of the pass-0 table in LDS, the other pass-0 twiddles formed as
+// their powers (tw0_load<POW>) -- where the whole table would cost the second workgroup of a CU (chs_fast_f32.hip)
 template <class C>
-constexpr int col_tw_elems() {
-  return 2 * ((C::R0 - 1) * C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
+struct ColTwLds { static constexpr int value = 1; };
+template <class C>
+constexpr int col_tw_lds_elems() {
+  if (ColTwLds<C>::value == 1) return 2 * ((C::R0 - 1) * C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
+  if (ColTwLds<C>::value == 2) return 2 * (C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
+  return 0;
 }
-
-// k_col<MODE_STEP> keeps the pass twiddles in LDS unless a configuration says otherwise (chs_fast_f32.hip: where they
-// would cost the second workgroup of a CU)
-template <class C>
-struct ColTwLds { static constexpr bool value = true; };
 
 template <class C>
 constexpr int col_lds_elems() {
@@ -706,15 +707,22 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // behind the barriers of the stage-in): no L2 round trip per pass, and no load that would have to
   // wait behind the hat_U stores at the start of the inverse passes
   FTables<T> tbp = tb;
-  if constexpr (MODE == MODE_STEP && ColTwLds<C>::value) {
+  constexpr bool TW0POW = (MODE == MODE_STEP) && (ColTwLds<C>::value == 2);
+  if constexpr (MODE == MODE_STEP && ColTwLds<C>::value != 0) {
     T* ltw = lds + col_lds_elems<C>();
-    constexpr int NTW = col_tw_elems<C>();
-    for (int i = 2 * threadIdx.x; i < NTW; i += 2 * C::THREADS) {
-      if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(ltw + i) = *reinterpret_cast<const double2*>(tb.tw0 + i);
-      else *reinterpret_cast<float2*>(ltw + i) = *reinterpret_cast<const float2*>(tb.tw0 + i);
-    }
+    // pass-0 part (the whole table, or its k = 1 entries), then twa | twb (contiguous behind tw0 in the table buffer)
+    constexpr int N0 = TW0POW ? 2 * C::L1 : 2 * (C::R0 - 1) * C::L1;
+    constexpr int NM = col_tw_lds_elems<C>() - N0;
+    auto cp = [&](T* dst, const T* src, int n) {
+      for (int i = 2 * threadIdx.x; i < n; i += 2 * C::THREADS) {
+        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst + i) = *reinterpret_cast<const double2*>(src + i);
+        else *reinterpret_cast<float2*>(dst + i) = *reinterpret_cast<const float2*>(src + i);
+      }
+    };
+    cp(ltw, tb.tw0, N0);
+    cp(ltw + N0, tb.twa, NM);
     tbp.tw0 = ltw;
-    tbp.twa = ltw + 2 * (C::R0 - 1) * C::L1;
+    tbp.twa = ltw + N0;
     tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
   }
   T* hcol = hat + (size_t)kcp * C::N;
@@ -803,7 +811,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     }
     __syncthreads();
     if constexpr (MODE == MODE_STEP) STAMP(1, 1);
-    fwd_passes<C>(z, scr, tbp, l);
+    fwd_passes<C, TW0POW>(z, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 2);
     if constexpr (MODE == MODE_STEP) {
       // Gated tail: the bookkeeping of the previous step -- stop rules, adaptive time step -- runs as block 0
@@ -899,7 +907,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   }
   if constexpr (MODE == MODE_STEP) STAMP(1, 3);
   if constexpr (ADJ) {
-    inv_passes<C>(z, scr, tbp, l);
+    inv_passes<C, TW0POW>(z, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 4);
     // ---- stage out: quads -> tile rows
     T* tile = Tout + (size_t)ct * C::N * C::CT;
@@ -982,7 +990,7 @@ struct Launch {
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
   static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(T) / 2 <= row_lds) && (C::R0 % 4 == 0);
   // staging / exchange scratch + the pass twiddles (k_col<MODE_STEP>)
-  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (ColTwLds<CC>::value ? (size_t)col_tw_elems<CC>() : 0)) * sizeof(T);
+  static constexpr size_t col_lds = ((size_t)col_lds_elems<CC>() + (size_t)col_tw_lds_elems<CC>()) * sizeof(T);
   static_assert(C::N == CC::N && C::CT == CC::CT, "row/column configs must agree on the tile layout");
 
   template <class K>
