@@ -28,6 +28,10 @@
 using G8192 = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT>;
 using G8192C = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
 template <> struct ColTwLds<G8192C> { static constexpr int value = CHS_G8192C_TW_LDS; };
+#ifndef CHS_G8192_ROW_TW_LDS
+#define CHS_G8192_ROW_TW_LDS 1
+#endif
+template <> struct RowTwLds<G8192> { static constexpr bool value = (CHS_G8192_ROW_TW_LDS != 0); };
 #ifndef CHS_G4096_THREADS
 #define CHS_G4096_THREADS 256
 #endif

@@ -216,6 +216,16 @@ extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 #define CHS_COL_ZIGZAG 1  // k_col walks the tiles in alternating direction from step to step (Infinity Cache)
 #endif
 
+// The fused row kernel takes its pass twiddles from L2 (its four workgroups per CU leave no LDS) unless a configuration
+// has room for the compact form: the k = 1 entries of the pass-0 table + the middle-pass tables, the other pass-0
+// twiddles as powers (tw0_load<POW>)
+template <class C>
+struct RowTwLds { static constexpr bool value = false; };
+template <class C>
+constexpr int row_tw_lds_elems() {
+  return RowTwLds<C>::value ? 2 * (C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0)) : 0;
+}
+
 // Returns x through an opaque asm so that index arithmetic derived from it is not CSE'd
 // with (and kept alive since) an earlier phase of the kernel: recomputing a few integer
 // offsets is far cheaper than holding dozens of address registers across a phase.
@@ -406,6 +416,19 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
     if constexpr (C::WAVE_LOCAL) __syncthreads();  // (no block barrier before the pointwise part otherwise)
   }
+  // pass twiddles from LDS where the configuration has room (RowTwLds): visible behind the first exchange barrier of
+  // the inverse passes, whose last-pass butterflies come first and need none
+  constexpr bool RTW = DIAG && FUSE && RowTwLds<C>::value && !C::WAVE_LOCAL;
+  FTables<T> tbp = tb;
+  if constexpr (RTW) {
+    T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16);
+    constexpr int N0 = 2 * C::L1, NM = row_tw_lds_elems<C>() - N0;
+    for (int i = 2 * threadIdx.x; i < N0; i += 2 * C::THREADS) *reinterpret_cast<v2f*>(ltw + i) = *reinterpret_cast<const v2f*>(tb.tw0 + i);
+    for (int i = 2 * threadIdx.x; i < NM; i += 2 * C::THREADS) *reinterpret_cast<v2f*>(ltw + N0 + i) = *reinterpret_cast<const v2f*>(tb.twa + i);
+    tbp.tw0 = ltw;
+    tbp.twa = ltw + N0;
+    tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
+  }
   const int row0 = row_of_block<C>(blockIdx.x);
   const int row = row0 + sub;
   T* scr = lds + (size_t)sub * C::SCR;
@@ -418,7 +441,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     Ya = cx_make(y[0], y[1]); Yb = cx_make(y[2], y[3]);
   }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
-  inv_passes<C>(z, scr, tb, launder(l));
+  inv_passes<C, RTW>(z, scr, tbp, launder(l));
   if constexpr (DIAG && FUSE) STAMP(0, 2);
   __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
   const unsigned urow = (unsigned)row * C::N;
@@ -570,7 +593,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   if constexpr (DIAG && FUSE) STAMP(0, 4);
   if constexpr (FUSE) {
     __builtin_amdgcn_sched_barrier(0);
-    fwd_passes<C>(z, scr, tb, launder(l));
+    fwd_passes<C, RTW>(z, scr, tbp, launder(l));
     if constexpr (DIAG && FUSE) STAMP(0, 5);
     __builtin_amdgcn_sched_barrier(0);
     recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
@@ -986,7 +1009,7 @@ static FTables<T> get_tables(Engine* E) {
 template <class C, class CC = C>
 struct Launch {
   using T = typename C::T;
-  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16;
+  static constexpr size_t row_lds = (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16 + (size_t)row_tw_lds_elems<C>() * sizeof(T);
   // the fused row kernel can add up the adaptive-step integrand per column itself (chs_fast_step)
   static constexpr bool ADAPT_OK = (C::C <= 4) && (C::C == 1 || (size_t)C::N * sizeof(T) / 2 <= row_lds) && (C::R0 % 4 == 0);
   // staging / exchange scratch + the pass twiddles (k_col<MODE_STEP>)
