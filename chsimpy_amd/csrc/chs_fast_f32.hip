@@ -29,9 +29,9 @@ using G8192 = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192_WPS
 using G8192C = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
 template <> struct ColTwLds<G8192C> { static constexpr int value = CHS_G8192C_TW_LDS; };
 #ifndef CHS_G8192_ROW_TW_LDS
-#define CHS_G8192_ROW_TW_LDS 1
+#define CHS_G8192_ROW_TW_LDS 2
 #endif
-template <> struct RowTwLds<G8192> { static constexpr bool value = (CHS_G8192_ROW_TW_LDS != 0); };
+template <> struct RowTwLds<G8192> { static constexpr int value = CHS_G8192_ROW_TW_LDS; };
 #ifndef CHS_G4096_THREADS
 #define CHS_G4096_THREADS 256
 #endif
@@ -39,6 +39,10 @@ template <> struct RowTwLds<G8192> { static constexpr bool value = (CHS_G8192_RO
 // k_col and 6 % slower in the rows)
 using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, CHS_F32_CT>;
 using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, CHS_F32_CT>;
+#ifndef CHS_G4096_ROW_TW_LDS
+#define CHS_G4096_ROW_TW_LDS 3
+#endif
+template <> struct RowTwLds<G4096> { static constexpr int value = CHS_G4096_ROW_TW_LDS; };
 // fp32 below N = 4096: the shapes of the fp64 configurations (groups inside one wavefront)
 // (8 complex values per lane with radix-4 end passes and small workgroups, as in fp64: chs_fast_f64.hip)
 using G128 = FCfg<float, 128, 8, 64, 4, 4, 1, 4, 1, 0, 1, 2>;
@@ -52,6 +56,8 @@ using G512C = FCfg<float, 512, 32, 64, 4, 4, 4, 4, 1, 1, 1, 2, 4>;
 #define CHS_F32_CT_SMALL 8  // N = 2048 fp32: 8 columns per tile (32-byte row pieces; +7 % against 4)
 #endif
 using G2048 = FCfg<float, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2, (CHS_F32_CT_SMALL ? CHS_F32_CT_SMALL : 4)>;
+// (row-kernel twiddles in LDS: 26.5 k -> 23.5-24.2 k steps/s here: a copy and a block barrier per workgroup for groups that
+// otherwise need none)
 
 bool chs_fast_bind_f32(int N, FastPlan* P) {
   switch (N) {

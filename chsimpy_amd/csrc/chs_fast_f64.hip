@@ -20,6 +20,7 @@ using F1024 = FCfg<double, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
 // N = 2048: 16 complex values per lane (an 8-per-lane variant with two wavefronts per transform measured equal)
 using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 using F2048C = F2048;
+// (the pass twiddles of the row kernel in LDS, which pay from N = 4096 upwards, cost 1 % here: 17.1 k against 17.25 k steps/s)
 // N = 4096: two wavefronts per transform, 16 complex values per lane, four radix passes
 #ifndef CHS_ROW_WPS
 #define CHS_ROW_WPS 4
@@ -29,7 +30,7 @@ using F2048C = F2048;
 #endif
 // row kernels: CHS_ROW_THREADS/128 rows per workgroup, tiles of 4 columns
 #ifndef CHS_ROW_PADL
-#define CHS_ROW_PADL 16
+#define CHS_ROW_PADL 4   // (16 before round 3: 2 KB of scratch per workgroup that the middle-pass twiddles now use)
 #endif
 #ifndef CHS_F4096_CT
 #define CHS_F4096_CT 4  // columns per tile of the T layout (8: 64-byte row pieces; measured)
@@ -44,6 +45,13 @@ using F2048C = F2048;
 #define CHS_COL_PADL 16
 #endif
 using F4096 = FCfg<double, 4096, 128, CHS_ROW_THREADS, 8, 4, 8, 8, CHS_PAD1, CHS_PAD2, CHS_ROW_PADL, CHS_ROW_WPS, CHS_F4096_CT>;
+// The fused row kernel keeps the twiddles of its two middle passes in LDS (4 KB; with the pad of the last exchange at 4
+// instead of 16 four workgroups still fit a CU: 4 x 39.8 KB): row kernel 102.6 -> 94.4 us, 4544 -> 4750 steps/s on one
+// box (profiles/r03_ab_occupancy.txt); the smaller pad alone changes nothing.
+#ifndef CHS_F4096_ROW_TW_LDS
+#define CHS_F4096_ROW_TW_LDS 3
+#endif
+template <> struct RowTwLds<F4096> { static constexpr int value = CHS_F4096_ROW_TW_LDS; };
 // k_col runs best with the full register file of two waves per SIMD (no spills; the compiler
 // uses the room to keep more loads in flight): measured 305 -> 191 us per launch
 #ifndef CHS_COL_WPS
@@ -68,6 +76,10 @@ template <> struct ColTwLds<F4096C> { static constexpr int value = CHS_F4096C_TW
 #endif
 using F8192 = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 4, CHS_F8192_CT>;
 using F8192C = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 2, CHS_F8192_CT>;
+#ifndef CHS_F8192_ROW_TW_LDS
+#define CHS_F8192_ROW_TW_LDS 3
+#endif
+template <> struct RowTwLds<F8192> { static constexpr int value = CHS_F8192_ROW_TW_LDS; };
 
 
 bool chs_fast_bind_f64(int N, FastPlan* P) {

@@ -219,11 +219,14 @@ extern __shared__ __attribute__((aligned(16))) unsigned char chs_dyn_lds[];
 // The fused row kernel takes its pass twiddles from L2 (its four workgroups per CU leave no LDS) unless a configuration
 // has room for the compact form: the k = 1 entries of the pass-0 table + the middle-pass tables, the other pass-0
 // twiddles as powers (tw0_load<POW>)
+// (value 2), for the middle-pass tables alone (value 3; the pass-0 table stays in L2), or for all of them (value 1)
 template <class C>
-struct RowTwLds { static constexpr bool value = false; };
+struct RowTwLds { static constexpr int value = 0; };
 template <class C>
 constexpr int row_tw_lds_elems() {
-  return RowTwLds<C>::value ? 2 * (C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0)) : 0;
+  constexpr int mid = 2 * ((C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
+  constexpr int v = RowTwLds<C>::value;
+  return v == 1 ? 2 * (C::R0 - 1) * C::L1 + mid : (v == 2 ? 2 * C::L1 + mid : (v == 3 ? mid : 0));
 }
 
 // Returns x through an opaque asm so that index arithmetic derived from it is not CSE'd
@@ -414,21 +417,30 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
   if constexpr (DIAG && sizeof(T) == 8) {
     for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
-    if constexpr (C::WAVE_LOCAL) __syncthreads();  // (no block barrier before the pointwise part otherwise)
   }
   // pass twiddles from LDS where the configuration has room (RowTwLds): visible behind the first exchange barrier of
   // the inverse passes, whose last-pass butterflies come first and need none
-  constexpr bool RTW = DIAG && FUSE && RowTwLds<C>::value && !C::WAVE_LOCAL;
+  constexpr int RTWM = (DIAG && FUSE) ? RowTwLds<C>::value : 0;
+  constexpr bool RTW = (RTWM == 2);   // pass-0 twiddles by powers
   FTables<T> tbp = tb;
-  if constexpr (RTW) {
+  if constexpr (RTWM != 0) {
     T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16);
-    constexpr int N0 = 2 * C::L1, NM = row_tw_lds_elems<C>() - N0;
-    for (int i = 2 * threadIdx.x; i < N0; i += 2 * C::THREADS) *reinterpret_cast<v2f*>(ltw + i) = *reinterpret_cast<const v2f*>(tb.tw0 + i);
-    for (int i = 2 * threadIdx.x; i < NM; i += 2 * C::THREADS) *reinterpret_cast<v2f*>(ltw + N0 + i) = *reinterpret_cast<const v2f*>(tb.twa + i);
-    tbp.tw0 = ltw;
+    constexpr int N0 = RTW ? 2 * C::L1 : (RTWM == 1 ? 2 * (C::R0 - 1) * C::L1 : 0), NM = row_tw_lds_elems<C>() - N0;
+    auto cp = [&](T* dst, const T* src, int n) {
+      for (int i = 2 * threadIdx.x; i < n; i += 2 * C::THREADS) {
+        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst + i) = *reinterpret_cast<const double2*>(src + i);
+        else *reinterpret_cast<v2f*>(dst + i) = *reinterpret_cast<const v2f*>(src + i);
+      }
+    };
+    cp(ltw, tb.tw0, N0);
+    cp(ltw + N0, tb.twa, NM);
+    if constexpr (N0 != 0) tbp.tw0 = ltw;
     tbp.twa = ltw + N0;
     tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
   }
+  // (groups inside one wavefront exchange behind wavefront fences only: no block barrier would make the log table and
+  // the twiddles visible before their first use)
+  if constexpr (C::WAVE_LOCAL && ((DIAG && sizeof(T) == 8) || RTWM != 0)) __syncthreads();
   const int row0 = row_of_block<C>(blockIdx.x);
   const int row = row0 + sub;
   T* scr = lds + (size_t)sub * C::SCR;
