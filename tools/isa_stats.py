@@ -16,7 +16,7 @@ def main():
     flt = [a for a in sys.argv[2:] if not a.startswith('-')]
     extra = [a for a in sys.argv[2:] if a.startswith('-')]
     out = '/tmp/isa_stats_%d.s' % os.getpid()
-    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-Wno-unused-value', '-Wno-unused-result',
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-Wno-unused-value', '-Wno-unused-result', '-Wno-pass-failed',
            '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'chsimpy_amd', 'csrc'),
            '--cuda-device-only', '-S', src, '-o', out] + extra
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
