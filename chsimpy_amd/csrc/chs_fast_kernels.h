@@ -229,6 +229,31 @@ constexpr int row_tw_lds_elems() {
   return v == 1 ? 2 * (C::R0 - 1) * C::L1 + mid : (v == 2 ? 2 * C::L1 + mid : (v == 3 ? mid : 0));
 }
 
+// The row kernels' LDS copy of their pass twiddles (RowTwLds), behind the exchange scratch and the log table; returns the
+// table set to use.  The caller provides the barrier between the copy and the first use.
+template <class C>
+__device__ __forceinline__ FTables<typename C::T> row_twiddles_to_lds(const FTables<typename C::T>& tb) {
+  using T = typename C::T;
+  constexpr int RTWM = RowTwLds<C>::value;
+  FTables<T> tbp = tb;
+  if constexpr (RTWM != 0) {
+    T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16);
+    constexpr int N0 = (RTWM == 2) ? 2 * C::L1 : (RTWM == 1 ? 2 * (C::R0 - 1) * C::L1 : 0), NM = row_tw_lds_elems<C>() - N0;
+    auto cp = [&](T* dst, const T* src, int n) {
+      for (int i = 2 * threadIdx.x; i < n; i += 2 * C::THREADS) {
+        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst + i) = *reinterpret_cast<const double2*>(src + i);
+        else *reinterpret_cast<v2f*>(dst + i) = *reinterpret_cast<const v2f*>(src + i);
+      }
+    };
+    cp(ltw, tb.tw0, N0);
+    cp(ltw + N0, tb.twa, NM);
+    if constexpr (N0 != 0) tbp.tw0 = ltw;
+    tbp.twa = ltw + N0;
+    tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
+  }
+  return tbp;
+}
+
 // Returns x through an opaque asm so that index arithmetic derived from it is not CSE'd
 // with (and kept alive since) an earlier phase of the kernel: recomputing a few integer
 // offsets is far cheaper than holding dozens of address registers across a phase.
@@ -257,6 +282,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
   row_lane_map<C>(l, sub);
   const int row = row_of_block<C>(blockIdx.x) + sub;
   T* scr = lds + (size_t)sub * C::SCR;
+  constexpr int RTWM = RowTwLds<C>::value;
+  const FTables<T> tbp = row_twiddles_to_lds<C>(tb);
+  if constexpr (RTWM != 0) __syncthreads();
   typename C::V z[C::E];
   double s2 = 0.0;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
@@ -297,7 +325,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
     }
     if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of this step becomes NaN
   }
-  fwd_passes<C>(z, scr, tb, l);
+  fwd_passes<C, (RTWM == 2)>(z, scr, tbp, l);
   recombine<C, true, false, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
                             [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
     if (live) {
@@ -336,8 +364,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
   double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
   if constexpr (sizeof(T) == 8) {
     for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
-    __syncthreads();
   }
+  // pass twiddles from LDS where the configuration has room (RowTwLds, as in the fused row kernel: at N=8192 fp32,
+  // 30 twiddle loads per radix-16 butterfly, this kernel took 511 us with them in L2)
+  constexpr int RTWM = RowTwLds<C>::value;
+  constexpr bool RTW = (RTWM == 2);
+  const FTables<T> tbp = row_twiddles_to_lds<C>(tb);
+  if constexpr (sizeof(T) == 8 || RTWM != 0) __syncthreads();  // the log table and the twiddles are visible
   typename C::V z[C::E];
   double s2 = 0.0;
   unsigned dom = 0;
@@ -375,7 +408,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
       if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of the first step becomes NaN
     }
     T* dst = pass ? T1 : Ta;
-    fwd_passes<C>(z, scr, tb, launder(l));
+    fwd_passes<C, RTW>(z, scr, tbp, launder(l));
     recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
                               [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
       if (live) {
@@ -420,24 +453,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   }
   // pass twiddles from LDS where the configuration has room (RowTwLds): visible behind the first exchange barrier of
   // the inverse passes, whose last-pass butterflies come first and need none
-  constexpr int RTWM = (DIAG && FUSE) ? RowTwLds<C>::value : 0;
+  constexpr int RTWM = RowTwLds<C>::value;
   constexpr bool RTW = (RTWM == 2);   // pass-0 twiddles by powers
-  FTables<T> tbp = tb;
-  if constexpr (RTWM != 0) {
-    T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16);
-    constexpr int N0 = RTW ? 2 * C::L1 : (RTWM == 1 ? 2 * (C::R0 - 1) * C::L1 : 0), NM = row_tw_lds_elems<C>() - N0;
-    auto cp = [&](T* dst, const T* src, int n) {
-      for (int i = 2 * threadIdx.x; i < n; i += 2 * C::THREADS) {
-        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst + i) = *reinterpret_cast<const double2*>(src + i);
-        else *reinterpret_cast<v2f*>(dst + i) = *reinterpret_cast<const v2f*>(src + i);
-      }
-    };
-    cp(ltw, tb.tw0, N0);
-    cp(ltw + N0, tb.twa, NM);
-    if constexpr (N0 != 0) tbp.tw0 = ltw;
-    tbp.twa = ltw + N0;
-    tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
-  }
+  const FTables<T> tbp = row_twiddles_to_lds<C>(tb);
   // (groups inside one wavefront exchange behind wavefront fences only: no block barrier would make the log table and
   // the twiddles visible before their first use)
   if constexpr (C::WAVE_LOCAL && ((DIAG && sizeof(T) == 8) || RTWM != 0)) __syncthreads();
