@@ -25,7 +25,7 @@
 // compile-time configuration
 // ---------------------------------------------------------------------------
 template <typename T_, int N_, int G_, int THREADS_, int R0_, int RA_, int RB_, int RL_, int PAD1_, int PAD2_,
-          int PADL_, int WPS_, int CT_ = THREADS_ / G_>
+          int PADL_, int WPS_, int CT_ = THREADS_ / G_, int SPLIT_ = 0>
 struct FCfg {
   using T = T_;
   using V = Cx<T_>;  // the complex value type of the core
@@ -61,7 +61,7 @@ struct FCfg {
   // fp32: the real and the imaginary part of a value travel TOGETHER through the exchange scratch as one
   // 8-byte item (half the LDS instructions and half the barriers of an exchange; the scratch then holds
   // twice as many elements); fp64: one after the other through the same scratch (half the LDS)
-  static constexpr bool PAIR = (sizeof(T_) == 4);
+  static constexpr bool PAIR = (sizeof(T_) == 4) && !SPLIT_;
   // fp32: the columns of T in SLOT order (chs_fast_kernels.h: slot_boff) -- a lane's four coefficients of a slot are one
   // 16-byte access instead of four 4-byte ones.  fp64 keeps the natural column order: there a slot would be a whole
   // 32-byte sector written in two half-sector instructions by every lane, where the natural order has four lanes fill a

@@ -14,7 +14,7 @@
 // steps/s; this shape with all pass twiddles from L2 349 us, 1660; with the k = 1 entries in LDS 313 us, 1763; with the
 // whole table in LDS (one workgroup per CU) 475 us.  The rows take 252-254 us in either shape.
 #ifndef CHS_G8192_WPS
-#define CHS_G8192_WPS 2
+#define CHS_G8192_WPS 3
 #endif
 #ifndef CHS_G8192C_WPS
 #define CHS_G8192C_WPS 2
@@ -25,7 +25,15 @@
 #ifndef CHS_G8192C_TW_LDS
 #define CHS_G8192C_TW_LDS 2
 #endif
-using G8192 = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT>;
+// The row kernels exchange the real and the imaginary parts one after the other (as fp64 does): half the exchange
+// scratch, three workgroups per CU instead of two -- fused row kernel 217 -> 206 us (profiles/r03_ab_split.txt); k_col,
+// whose staging buffer is as large as its paired scratch, gains nothing from it (split exchanges with the whole pass-0
+// table in LDS: 343 against 316 us; with three workgroups per CU, 140 B of spills: 370-382; 4 columns per 512-thread
+// workgroup, 280 B of spills: 359).
+#ifndef CHS_G8192_SPLIT
+#define CHS_G8192_SPLIT 1
+#endif
+using G8192 = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT, CHS_G8192_SPLIT>;
 using G8192C = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
 template <> struct ColTwLds<G8192C> { static constexpr int value = CHS_G8192C_TW_LDS; };
 #ifndef CHS_G8192_ROW_TW_LDS
