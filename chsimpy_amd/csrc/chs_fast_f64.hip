@@ -76,6 +76,13 @@ template <> struct ColTwLds<F4096C> { static constexpr int value = CHS_F4096C_TW
 #endif
 using F8192 = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 4, CHS_F8192_CT>;
 using F8192C = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 2, CHS_F8192_CT>;
+// k_col (one 512-thread workgroup per CU either way): pass-0 twiddles as powers of the k = 1 entries in LDS 729-736 us,
+// the whole table in LDS 754-756, all from L2 767-768; one column per 256-thread workgroup, two per CU: 790-794
+// (profiles/r03_ab_f8192.txt)
+#ifndef CHS_F8192C_TW_LDS
+#define CHS_F8192C_TW_LDS 2
+#endif
+template <> struct ColTwLds<F8192C> { static constexpr int value = CHS_F8192C_TW_LDS; };
 #ifndef CHS_F8192_ROW_TW_LDS
 #define CHS_F8192_ROW_TW_LDS 3
 #endif
