@@ -25,7 +25,7 @@
 // compile-time configuration
 // ---------------------------------------------------------------------------
 template <typename T_, int N_, int G_, int THREADS_, int R0_, int RA_, int RB_, int RL_, int PAD1_, int PAD2_,
-          int PADL_, int WPS_, int CT_ = THREADS_ / G_, int SPLIT_ = 0>
+          int PADL_, int WPS_, int CT_ = THREADS_ / G_, int XPAIR_ = -1>
 struct FCfg {
   using T = T_;
   using V = Cx<T_>;  // the complex value type of the core
@@ -58,10 +58,11 @@ struct FCfg {
   static constexpr int SCR1 = (RA_ > 1) ? S1 * P1 : 0;
   static constexpr int SCR2 = (RB_ > 1) ? S2A * P2 : 0;
   static constexpr int SCRL = RL_ * PL;
-  // fp32: the real and the imaginary part of a value travel TOGETHER through the exchange scratch as one
-  // 8-byte item (half the LDS instructions and half the barriers of an exchange; the scratch then holds
-  // twice as many elements); fp64: one after the other through the same scratch (half the LDS)
-  static constexpr bool PAIR = (sizeof(T_) == 4) && !SPLIT_;
+  // PAIR: the real and the imaginary part of a value travel TOGETHER through the exchange scratch as one item of
+  // 2*sizeof(T) bytes (half the LDS instructions and half the barriers of an exchange; the scratch then holds twice
+  // as many elements); otherwise one after the other through the same scratch (half the LDS).  XPAIR_ < 0: the
+  // default of the element type (fp32 paired, fp64 split); 0 / 1: as given (chs_fast_f32.hip, chs_fast_f64.hip).
+  static constexpr bool PAIR = (XPAIR_ < 0) ? (sizeof(T_) == 4) : (XPAIR_ != 0);
   // fp32: the columns of T in SLOT order (chs_fast_kernels.h: slot_boff) -- a lane's four coefficients of a slot are one
   // 16-byte access instead of four 4-byte ones.  fp64 keeps the natural column order: there a slot would be a whole
   // 32-byte sector written in two half-sector instructions by every lane, where the natural order has four lanes fill a
@@ -355,9 +356,13 @@ __device__ __forceinline__ void mid_inv(typename C::V* z, const typename C::T* t
 // real parts, 1 = the imaginary parts
 template <class C, bool WR, int PART>
 __device__ __forceinline__ void xfer(typename C::V& v, typename C::T* scr, int addr) {
-  if constexpr (C::PAIR) {
+  if constexpr (C::PAIR && sizeof(typename C::T) == 4) {
     v2f* s2 = reinterpret_cast<v2f*>(scr);
     if constexpr (WR) s2[addr] = v; else v = s2[addr];
+  } else if constexpr (C::PAIR) {
+    double2* s2 = reinterpret_cast<double2*>(scr);  // one 16-byte LDS access
+    if constexpr (WR) s2[addr] = make_double2(v.x, v.y);
+    else { const double2 t = s2[addr]; v.x = t.x; v.y = t.y; }
   } else {
     if constexpr (WR) scr[addr] = PART ? v.y : v.x;
     else if constexpr (PART) v.y = scr[addr];

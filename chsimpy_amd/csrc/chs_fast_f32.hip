@@ -30,10 +30,10 @@
 // whose staging buffer is as large as its paired scratch, gains nothing from it (split exchanges with the whole pass-0
 // table in LDS: 343 against 316 us; with three workgroups per CU, 140 B of spills: 370-382; 4 columns per 512-thread
 // workgroup, 280 B of spills: 359).
-#ifndef CHS_G8192_SPLIT
-#define CHS_G8192_SPLIT 1
+#ifndef CHS_G8192_XPAIR
+#define CHS_G8192_XPAIR 0
 #endif
-using G8192 = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT, CHS_G8192_SPLIT>;
+using G8192 = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT, CHS_G8192_XPAIR>;
 using G8192C = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
 template <> struct ColTwLds<G8192C> { static constexpr int value = CHS_G8192C_TW_LDS; };
 #ifndef CHS_G8192_ROW_TW_LDS
@@ -47,6 +47,10 @@ template <> struct RowTwLds<G8192> { static constexpr int value = CHS_G8192_ROW_
 // k_col and 6 % slower in the rows)
 using G4096 = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 4, CHS_F32_CT>;
 using G4096C = FCfg<float, 4096, 128, CHS_G4096_THREADS, 8, 4, 8, 8, 2, 1, 16, 2, CHS_F32_CT>;
+#ifndef CHS_G4096C_TW_LDS
+#define CHS_G4096C_TW_LDS 2  // k = 1 entries + powers: k_col 63.5 -> 61.8 us against the whole table (profiles/r03_ab_tw2.txt)
+#endif
+template <> struct ColTwLds<G4096C> { static constexpr int value = CHS_G4096C_TW_LDS; };
 #ifndef CHS_G4096_ROW_TW_LDS
 #define CHS_G4096_ROW_TW_LDS 3
 #endif

@@ -18,6 +18,9 @@ using F512 = FCfg<double, 512, 32, 128, 4, 4, 4, 4, 1, 1, 1, 2>;
 using F512C = FCfg<double, 512, 32, 64, 4, 4, 4, 4, 1, 1, 1, 2, 4>;
 using F1024 = FCfg<double, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
 // N = 2048: 16 complex values per lane (an 8-per-lane variant with two wavefronts per transform measured equal)
+// (paired 16-byte exchange items, FCfg::PAIR, with k_col's pass-0 twiddles as powers to make room: 17.39 k -> 17.60 k
+// steps/s for a single run, at 76 instead of 35 KB of LDS per workgroup -- not taken: members of an ensemble share the
+// CUs; the powers alone: no change.  profiles/r03_ab_xpair.txt)
 using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 using F2048C = F2048;
 // (the pass twiddles of the row kernel in LDS, which pay from N = 4096 upwards, cost 1 % here: 17.1 k against 17.25 k steps/s)
@@ -61,9 +64,13 @@ template <> struct RowTwLds<F4096> { static constexpr int value = CHS_F4096_ROW_
 #define CHS_COL_THREADS 256
 #endif
 // k_col: CHS_COL_THREADS/128 of the 4 columns of a tile per workgroup
+// (paired 16-byte exchange items -- 27 instead of 39 barriers, 463 instead of 559 LDS instructions, 78 instead of 45 KB
+// of LDS -- measured equal: 4829 against 4829 steps/s over three interleaved rounds, profiles/r03_ab_xpair.txt)
 using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, CHS_PAD1, CHS_PAD2, CHS_COL_PADL, CHS_COL_WPS, CHS_F4096_CT>;
+// pass-0 twiddles: the k = 1 entries in LDS, the others as their powers (tw0_load<POW>): k_col 122-124 -> 119-121 us
+// against the whole table in LDS (profiles/r03_ab_tw2.txt); all from L2: 139 us
 #ifndef CHS_F4096C_TW_LDS
-#define CHS_F4096C_TW_LDS 1
+#define CHS_F4096C_TW_LDS 2
 #endif
 template <> struct ColTwLds<F4096C> { static constexpr int value = CHS_F4096C_TW_LDS; };
 

@@ -1,13 +1,14 @@
 #!/bin/bash
 # A/B timing of prebuilt library variants on one GPU box (box-to-box clocks differ by a few %):
 #   tools/ab.sh [rounds] [bench args...]  -- runs bench.py with every chsimpy_amd/lib/variants/*.so, interleaved
+#   (AB_GLOB='[ab]_*' restricts the variants)
 rounds=${1:-2}
 shift
 args=${@:---steps 300 --warmup 300}
 mkdir -p gpurun_out
 : > gpurun_out/ab.log
 for r in $(seq $rounds); do
-  for v in chsimpy_amd/lib/variants/*.so; do
+  for v in chsimpy_amd/lib/variants/${AB_GLOB:-*}.so; do
     cp $v chsimpy_amd/lib/libchs_hip.so
     timeout -k 10 200 python bench.py --no-cpu-baseline $args > gpurun_out/ab_one.log 2>&1 || { echo "$v failed"; tail -3 gpurun_out/ab_one.log; continue; }
     python - "$v" <<'PY' | tee -a gpurun_out/ab.log
