@@ -114,13 +114,19 @@ __device__ __forceinline__ void load4(const T* p, T q[4]);
 template <typename T>
 __device__ __forceinline__ void store4(T* p, const T q[4]);
 // the four coefficients y[t] <-> columns idx[t] of row r of a tile-major array: slot (pbase, l) of a row kernel
-template <class C>
+template <typename T>
+__device__ __forceinline__ void store4_nt(T* p, const T q[4]);
+template <class C, bool NT = false>
 __device__ __forceinline__ void row_store(typename C::T* base, unsigned r, int pbase, int l, const int* idx, const typename C::T y[4]) {
   if constexpr (C::SLOT) {
-    store4<typename C::T>(at_boff(base, slot_boff<C>(r, pbase, l)), y);
+    if constexpr (NT) store4_nt<typename C::T>(at_boff(base, slot_boff<C>(r, pbase, l)), y);
+    else store4<typename C::T>(at_boff(base, slot_boff<C>(r, pbase, l)), y);
   } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *at_boff(base, tile_boff<C>(r, idx[t])) = y[t];
+    for (int t = 0; t < 4; ++t) {
+      if constexpr (NT) __builtin_nontemporal_store(y[t], at_boff(base, tile_boff<C>(r, idx[t])));
+      else *at_boff(base, tile_boff<C>(r, idx[t])) = y[t];
+    }
   }
 }
 template <class C>
@@ -187,6 +193,36 @@ __device__ __forceinline__ void load4(const T* p, T q[4]) {
   } else {
     const float4 a = *reinterpret_cast<const float4*>(p);
     q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
+  }
+}
+// U at the borders of a call is streamed once (read by the entry kernel, written by the last row kernel): non-temporal
+// accesses, so that it does not displace T and hat_U from the caches the step loop lives in (the driver's 20-step
+// literal call: 4368 -> 4450 steps/s, profiles/r03_ab_nt.txt)
+typedef double chs_d2v __attribute__((ext_vector_type(2)));
+typedef float chs_f4v __attribute__((ext_vector_type(4)));
+typedef float chs_f2v __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void load4_nt(const T* p, T q[4]) {
+  if constexpr (sizeof(T) == 8) {
+    const chs_d2v a = __builtin_nontemporal_load(reinterpret_cast<const chs_d2v*>(p));
+    const chs_d2v b = __builtin_nontemporal_load(reinterpret_cast<const chs_d2v*>(p + 2));
+    q[0] = a.x; q[1] = a.y; q[2] = b.x; q[3] = b.y;
+  } else {
+    const chs_f4v a = __builtin_nontemporal_load(reinterpret_cast<const chs_f4v*>(p));
+    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const T q[4]);
+template <typename T>
+__device__ __forceinline__ void store4_nt(T* p, const T q[4]) {
+  if constexpr (sizeof(T) == 8) {
+    chs_d2v a, b; a.x = q[0]; a.y = q[1]; b.x = q[2]; b.y = q[3];
+    __builtin_nontemporal_store(a, reinterpret_cast<chs_d2v*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<chs_d2v*>(p + 2));
+  } else {
+    chs_f4v a; a.x = q[0]; a.y = q[1]; a.z = q[2]; a.w = q[3];
+    __builtin_nontemporal_store(a, reinterpret_cast<chs_f4v*>(p));
   }
 }
 template <typename T>
@@ -385,8 +421,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
 #pragma unroll
       for (int j = 0; j < C::R0 / 2; ++j) {
         T q1[4], q2[4];
-        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+        if (pass == 1) {  // the last read of this row
+          load4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+          load4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+        } else {
+          load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+          load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+        }
         pack_quads<C>(q1, q2, q, j, z);
       }
     }
@@ -413,7 +454,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
                               [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
       if (live) {
         const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
-        row_store<C>(dst, launder(row), pbase, launder(l), idx, y);
+        // Ta is read once, by k_col<FWD_NATIVE> right behind this kernel: streamed like U (driver protocol 4471 -> 4533
+        // steps/s, profiles/r03_ab_nt.txt); T1 is the first step's operand and stays cached
+        if (pass == 0) row_store<C, true>(dst, launder(row), pbase, launder(l), idx, y);
+        else row_store<C>(dst, launder(row), pbase, launder(l), idx, y);
       }
     }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
     __builtin_amdgcn_sched_barrier(0);
@@ -490,8 +534,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       for (int j = 0; j < C::R0 / 2; ++j) {
         T q1[4], q2[4];
         unpack_quads<C>(z, q, j, q1, q2);
-        store4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-        store4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+        store4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+        store4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
       }
     }
   }
@@ -822,10 +866,19 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       for (int i = 0; i < PER; ++i) {
         const int f = PW * (threadIdx.x + i * C::THREADS);
         const T* src = tile + CS::goff(rho, f, hh);
+        constexpr bool NT = (MODE == MODE_FWD_NATIVE);  // the entry's intermediate (k_row_fwd2's Ta): its only read
         if constexpr (PW == 1) {
-          stage[rho][i] = *src;
+          stage[rho][i] = NT ? __builtin_nontemporal_load(src) : *src;
         } else if constexpr (sizeof(T) == 8) {
-          const double2 v = *reinterpret_cast<const double2*>(src);
+          if constexpr (NT) {
+            const chs_d2v v = __builtin_nontemporal_load(reinterpret_cast<const chs_d2v*>(src));
+            stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
+          } else {
+            const double2 v = *reinterpret_cast<const double2*>(src);
+            stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
+          }
+        } else if constexpr (NT) {
+          const chs_f2v v = __builtin_nontemporal_load(reinterpret_cast<const chs_f2v*>(src));
           stage[rho][2 * i] = v.x; stage[rho][2 * i + 1] = v.y;
         } else {
           const float2 v = *reinterpret_cast<const float2*>(src);
