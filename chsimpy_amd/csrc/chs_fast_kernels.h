@@ -525,8 +525,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   // FUSE: between the steps of one call nothing reads U from HBM (the next step continues from the
   // registers) except the tail's np.gradient row-edge terms, which look at rows 0, 1, N-2, N-1: with
   // store_u == 0 only the workgroups owning those rows write them (chs_fast_step decides).
+  // The whole field at the end of a call (FUSE with store_u) is streamed out: nothing on the device reads it before
+  // the next call's entry.  The edge rows of every step and the field of the unfused pipeline are read right away
+  // (tail, k_diag, k_row_fwd): ordinary stores.
   const bool write_u = !FUSE || store_u || row0 < 2 || row0 + C::C > C::N - 2;
-  if (write_u) {
+  auto put_u = [&](auto nt) {
 #pragma unroll
     for (int q = 0; q < C::NP0; ++q) {
       const int m1 = ls + C::G * q, m2 = C::L1 - 1 - m1;
@@ -534,11 +537,15 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       for (int j = 0; j < C::R0 / 2; ++j) {
         T q1[4], q2[4];
         unpack_quads<C>(z, q, j, q1, q2);
-        store4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-        store4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+        T* p1 = at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T));
+        T* p2 = at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T));
+        if constexpr (decltype(nt)::value) { store4_nt<T>(p1, q1); store4_nt<T>(p2, q2); }
+        else { store4<T>(p1, q1); store4<T>(p2, q2); }
       }
     }
-  }
+  };
+  if (FUSE && store_u) put_u(std::true_type{});
+  else if (write_u) put_u(std::false_type{});
   if constexpr (DIAG) {
     // np.gradient edge columns: (U[r,1]-U[r,0]) and (U[r,N-1]-U[r,N-2]) live in lane 0
     if (ls == 0) {
