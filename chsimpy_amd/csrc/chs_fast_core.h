@@ -240,6 +240,20 @@ __device__ __forceinline__ Cx<T> ldc(const T* __restrict__ tab, int idx) {
   }
 }
 
+// the same with a non-temporal hint (operands that are touched once per pass over a grid no cache holds)
+typedef double chs_dv2 __attribute__((ext_vector_type(2)));
+template <typename T, bool NT>
+__device__ __forceinline__ Cx<T> ldc_hint(const T* __restrict__ tab, int idx) {
+  if constexpr (!NT) {
+    return ldc<T>(tab, idx);
+  } else if constexpr (sizeof(T) == 8) {
+    const chs_dv2 v = __builtin_nontemporal_load(reinterpret_cast<const chs_dv2*>(tab + 2 * (size_t)idx));
+    return cx_make(v.x, v.y);
+  } else {
+    return __builtin_nontemporal_load(reinterpret_cast<const v2f*>(tab + 2 * (size_t)idx));
+  }
+}
+
 // Group-level synchronisation of the LDS exchange.  A group inside one wavefront needs no
 // s_barrier (the LDS executes one wave's accesses in issue order): wavefront-scope fences
 // keep the COMPILER from moving LDS accesses across the hand-over point.  A group spanning
@@ -273,6 +287,17 @@ template <typename T>
 __device__ __forceinline__ void stc(T* __restrict__ tab, int idx, Cx<T> v) {
   if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(tab + 2 * (size_t)idx) = make_double2(v.x, v.y);
   else *reinterpret_cast<v2f*>(tab + 2 * (size_t)idx) = v;
+}
+template <typename T, bool NT>
+__device__ __forceinline__ void stc_hint(T* __restrict__ tab, int idx, Cx<T> v) {
+  if constexpr (!NT) {
+    stc<T>(tab, idx, v);
+  } else if constexpr (sizeof(T) == 8) {
+    chs_dv2 t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<chs_dv2*>(tab + 2 * (size_t)idx));
+  } else {
+    __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(tab + 2 * (size_t)idx));
+  }
 }
 
 // ---------------------------------------------------------------------------

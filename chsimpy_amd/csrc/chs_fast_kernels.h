@@ -843,6 +843,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // What the spectral stage reads per recombination slot (4 positions of this lane), fetched one slot
   // ahead: hat_U (two value pairs) and the eigenvalues / gradient weights of its four coefficients -- fp64:
   // {lambda_kr, sin^2(pi kr/N)} per coefficient (L2); fp32: one 16-byte entry of each per slot (FTables::lam4, sin4).
+  // Where T and hat_U together do not fit the 256 MiB Infinity Cache, hat_U -- touched once per step, here -- is
+  // streamed (non-temporal loads and stores) and T, which both kernels read and write, keeps the cache: N=8192 fp32
+  // (T = 256 MiB) fused row kernel 205 -> 174 us, k_col 313 -> 302 us, 1913 -> 2096 steps/s; at N=8192 fp64 nothing
+  // fits either way (no change); at N=4096 fp64 the two arrays are exactly the cache's size and streaming hat_U costs
+  // 4-6 % (profiles/r03_ab_nt.txt).  Loads or stores alone change nothing.
+  constexpr bool HAT_STREAM = 2 * (size_t)C::N * C::N * sizeof(T) > ((size_t)256 << 20);
+  constexpr bool HAT_NT_LD = HAT_STREAM, HAT_NT_ST = HAT_STREAM;
   struct Fetched64 { double2 ls[4]; Cx<T> h01, h23; };
   struct Fetched32 { float4 la, sa; Cx<T> h01, h23; };
   using Fetched = typename std::conditional<sizeof(T) == 8, Fetched64, Fetched32>::type;
@@ -856,8 +863,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       p.sa = reinterpret_cast<const float4*>(tb.sin4)[idx[4]];
     }
     const int hp = hat_pair_index<C>(pbase, fc_opaque(l));
-    p.h01 = ldc<T>(hcol, hp);
-    p.h23 = ldc<T>(hcol, hp + C::G);
+    p.h01 = ldc_hint<T, HAT_NT_LD>(hcol, hp);
+    p.h23 = ldc_hint<T, HAT_NT_LD>(hcol, hp + C::G);
     return p;
   };
   if constexpr (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE) {
@@ -986,8 +993,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       [&](int pbase, const int*, Cx<T>& Ya, Cx<T>& Yb, bool live) {
         if (live) {
           const int hp = hat_pair_index<C>(pbase, fc_opaque(l));
-          stc<T>(hout, hp, Ya);
-          stc<T>(hout, hp + C::G, Yb);
+          stc_hint<T, HAT_NT_ST>(hout, hp, Ya);
+          stc_hint<T, HAT_NT_ST>(hout, hp + C::G, Yb);
         }
       });
     if constexpr (sizeof(T) == 4) e2 = (double)e2v.x + (double)e2v.y;
