@@ -11,6 +11,13 @@
 
 #define CHS_WAVE 64
 
+// Cache policy of the step loop: T and hat_U together against the 256 MiB Infinity Cache of an
+// MI355X.  Where they exceed it, what is touched once per step (hat_U, the partial rows of the adaptive step) is moved
+// with non-temporal accesses and T, which both kernels read and write, keeps the cache.
+__host__ __device__ constexpr bool chs_grid_exceeds_cache(size_t N, size_t elem_bytes) {
+  return 2 * N * N * elem_bytes > ((size_t)256 << 20);
+}
+
 // ---------------------------------------------------------------------------
 // Device-resident scalar state of one simulation: what chsimpy/solver.py keeps
 // in `self.*` / `self.solution.*` between iterations, plus the reduction

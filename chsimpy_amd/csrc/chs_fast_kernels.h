@@ -660,7 +660,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
                   T g2 = chs_dt_integrand_fast(q2[e], dmax);
                   if (s < C::C - 1) { g1 += gl[o1 + e]; g2 += gl[o2 + e]; }
                   if (s > 0) { gl[o1 + e] = g1; gl[o2 + e] = g2; }
-                  else { prow[c1 + e] = g1; prow[c2 + e] = g2; }
+                  else if constexpr (chs_grid_exceeds_cache(C::N, sizeof(T))) {
+                    // written once, read once by the reduction kernels: streamed where the grid does not fit the cache
+                    // (N=8192 fp32 adaptive 1893 -> 1925 steps/s; N=4096 fp64, where it fits, 4119 -> 3974 if streamed)
+                    __builtin_nontemporal_store(g1, &prow[c1 + e]);
+                    __builtin_nontemporal_store(g2, &prow[c2 + e]);
+                  } else {
+                    prow[c1 + e] = g1; prow[c2 + e] = g2;
+                  }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one quad pair at a time: no pile-up of addresses and operands
               }
@@ -848,7 +855,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // (T = 256 MiB) fused row kernel 205 -> 174 us, k_col 313 -> 302 us, 1913 -> 2096 steps/s; at N=8192 fp64 nothing
   // fits either way (no change); at N=4096 fp64 the two arrays are exactly the cache's size and streaming hat_U costs
   // 4-6 % (profiles/r03_ab_nt.txt).  Loads or stores alone change nothing.
-  constexpr bool HAT_STREAM = 2 * (size_t)C::N * C::N * sizeof(T) > ((size_t)256 << 20);
+  constexpr bool HAT_STREAM = chs_grid_exceeds_cache(C::N, sizeof(T));
   constexpr bool HAT_NT_LD = HAT_STREAM, HAT_NT_ST = HAT_STREAM;
   struct Fetched64 { double2 ls[4]; Cx<T> h01, h23; };
   struct Fetched32 { float4 la, sa; Cx<T> h01, h23; };

@@ -518,7 +518,9 @@ int chs_launch_mu_colsums(Engine* E, int cs_offset) {
 #define CS_COLS 64
 #define CS_SLICES 32
 #define CS_UN 8
-template <typename PT>
+// STREAM: the rows are read past the caches (grids whose T and hat_U do not fit the Infinity Cache together: the
+// partial rows would displace T; where everything fits, the cached read is the faster one -- profiles/r03_ab_nt.txt)
+template <typename PT, bool STREAM>
 __global__ __launch_bounds__(PW_THREADS) void k_colsum_slices(const PT* __restrict__ partRows, int nRows, int N,
                                                               const DevState* __restrict__ st, int adaptive,
                                                               double* __restrict__ slices, int cs_offset) {
@@ -537,7 +539,11 @@ __global__ __launch_bounds__(PW_THREADS) void k_colsum_slices(const PT* __restri
     for (int rb = r0 + w; rb < r1; rb += NWV * CS_UN) {
       PT x[CS_UN];
 #pragma unroll
-      for (int u = 0; u < CS_UN; ++u) { const int r = rb + u * NWV; x[u] = col[(size_t)(r < r1 ? r : r0) * N]; }
+      for (int u = 0; u < CS_UN; ++u) {
+        const int r = rb + u * NWV;
+        const PT* src = &col[(size_t)(r < r1 ? r : r0) * N];
+        x[u] = STREAM ? __builtin_nontemporal_load(src) : *src;
+      }
 #pragma unroll
       for (int u = 0; u < CS_UN; ++u) s += (rb + u * NWV < r1) ? (double)x[u] : 0.0;
     }
@@ -576,10 +582,14 @@ __global__ __launch_bounds__(PW_THREADS) void k_colmin_slices(const double* __re
 static int launch_colmin(Engine* E, const void* rows, bool rows_f32, int nRows, int cs_offset) {
   if (!E->dColSlices) CHS_HIP(hipMalloc(&E->dColSlices, sizeof(double) * (size_t)CS_SLICES * E->N));
   const dim3 g1((E->N + CS_COLS - 1) / CS_COLS, CS_SLICES);
-  if (rows_f32)
-    k_colsum_slices<float><<<g1, PW_THREADS, 0, E->stream>>>((const float*)rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
-  else
-    k_colsum_slices<double><<<g1, PW_THREADS, 0, E->stream>>>((const double*)rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
+  const bool stream = chs_grid_exceeds_cache((size_t)E->N, E->dtype == CHS_F32 ? 4 : 8);
+  if (rows_f32) {
+    if (stream) k_colsum_slices<float, true><<<g1, PW_THREADS, 0, E->stream>>>((const float*)rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
+    else k_colsum_slices<float, false><<<g1, PW_THREADS, 0, E->stream>>>((const float*)rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
+  } else {
+    if (stream) k_colsum_slices<double, true><<<g1, PW_THREADS, 0, E->stream>>>((const double*)rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
+    else k_colsum_slices<double, false><<<g1, PW_THREADS, 0, E->stream>>>((const double*)rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
+  }
   k_colmin_slices<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dColSlices, E->N, E->dState, E->dc.adaptive_time,
                                                                   E->dPartColMin, cs_offset);
   E->nColMinCur = E->nColMinBlocks;
