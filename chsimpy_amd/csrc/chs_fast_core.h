@@ -601,10 +601,17 @@ __device__ __forceinline__ int fc_opaque(int x) {
 // waiting for the store too (one in-order vmcnt counter), so without this every slot would sit out the full
 // latency of the previous slot's stores.  !PIPE: everything of slot k is fetched in slot k (f may load and store
 // as it likes, st is empty).
-template <class C, bool FWD, bool ADJ, bool PIPE, class PRE, class F, class ST>
+// PREALL (small grids, PreAll<C>): the twiddles and fetches of ALL slots are requested before the first slot is
+// computed -- a small grid is a handful of workgroups with nothing to overlap with, and slot by slot every request is a
+// round trip to L2 that nothing hides (N=512: 4-5 round trips in a row per kernel); the registers are there.
+template <class C>
+struct PreAll { static constexpr bool value = (C::E <= 8); };
+template <class C, bool FWD, bool ADJ, bool PIPE_, class PRE, class F, class ST>
 __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typename C::T>& tb, int l, PRE&& pre, F&& f, ST&& st) {
   using T = typename C::T;
   using V = typename C::V;
+  constexpr bool PREALL = PreAll<C>::value;
+  constexpr bool PIPE = PIPE_ && !PREALL;
   constexpr int R2 = C::R2, N = C::N, M = C::M, H = R2 / 2;
   const V zero = cx_make(T(0), T(0));
 #pragma unroll
@@ -622,9 +629,20 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
       SlotTw<T> wn;
       const int id0[5] = {kap, N - kap, M - kap, M + kap, kap};
       decltype(pre(0, id0)) pn;
+      [[maybe_unused]] SlotTw<T> wv[PREALL ? R2 : 1];
+      [[maybe_unused]] decltype(pre(0, id0)) pv[PREALL ? R2 : 1];
       if constexpr (PIPE) {
         wn = slot_tw<T>(tb, kap);
         pn = pre(q * R2 * 4, id0);
+      }
+      if constexpr (PREALL) {
+#pragma unroll
+        for (int k = 0; k < R2; ++k) {
+          const int kk = kap + C::S2 * k;
+          wv[k] = slot_tw<T>(tb, kk);
+          const int idc[5] = {kk, N - kk, M - kk, M + kk, kk};
+          pv[k] = pre((q * R2 + k) * 4, idc);
+        }
       }
       CHS_RSTAMP1(0);
 #pragma unroll
@@ -632,7 +650,9 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
         if (k == 1) CHS_RSTAMP1(1);
         if (k == 4) CHS_RSTAMP1(2);
         const int kk = kap + C::S2 * k;
-        if (!PIPE) {
+        if constexpr (PREALL) {
+          wn = wv[k]; pn = pv[k];
+        } else if (!PIPE) {
           wn = slot_tw<T>(tb, kk);
           const int idc[5] = {kk, N - kk, M - kk, M + kk, kk};
           pn = pre((q * R2 + k) * 4, idc);
@@ -674,17 +694,39 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
       const int id0[5] = {o1, o2, o3, o4, (PIPE && sp) ? M + 1 : kk0};
       decltype(pre(0, id0)) pn;
       SlotTw<T> whp = SlotTw<T>();
+      [[maybe_unused]] SlotTw<T> wv[PREALL ? R2 : 1];
+      [[maybe_unused]] decltype(pre(0, id0)) pv[PREALL ? R2 : 1];
+      [[maybe_unused]] SlotTw<T> w0v = SlotTw<T>();
+      [[maybe_unused]] decltype(pre(0, id0)) p0v;
       if constexpr (PIPE) {  // slot 0 of the loop below, requested ahead of the special lane's own slot
         wn = slot_tw<T>(tb, o1);
         pn = pre(q * R2 * 4, id0);
         if (sp) whp = slot_tw<T>(tb, M / 2);  // the special lane's second self-paired butterfly
+      }
+      if constexpr (PREALL) {
+        // every lane requests its R2 slots; the special lane's dead slot 0 asks for a valid index (kk_of(0)) and its
+        // own slot's operands ride in the same burst
+        if (sp) {
+          const int ido[5] = {0, M / 2, M, 3 * (M / 2), M + 1};
+          w0v = slot_tw<T>(tb, 0); whp = slot_tw<T>(tb, M / 2);
+          p0v = pre(q * R2 * 4, ido);
+        }
+#pragma unroll
+        for (int k = 0; k < R2; ++k) {
+          const int kk = kk_of(k);
+          wv[k] = slot_tw<T>(tb, kk);
+          const int idc[5] = {kk, N - kk, M - kk, M + kk, kk};
+          pv[k] = pre((q * R2 + k) * 4, idc);
+        }
       }
       CHS_RSTAMP(0);
       if (sp) {
         const int idx[5] = {0, M / 2, M, 3 * (M / 2), M + 1};
         SlotTw<T> w0, wh;
         decltype(pre(0, id0)) p0;
-        if constexpr (PIPE) {
+        if constexpr (PREALL) {
+          w0 = w0v; wh = whp; p0 = p0v;
+        } else if constexpr (PIPE) {
           w0 = wn; wh = whp; p0 = pn;
         } else {
           w0 = slot_tw<T>(tb, 0); wh = slot_tw<T>(tb, M / 2);
@@ -714,7 +756,9 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
         if (k == 1) CHS_RSTAMP(2);
         if (k == 4) CHS_RSTAMP(3);
         const int kk = kk_of(k);
-        if (!PIPE) {
+        if constexpr (PREALL) {
+          wn = wv[k]; pn = pv[k];
+        } else if (!PIPE) {
           wn = slot_tw<T>(tb, kk);
           const int idc[5] = {kk, N - kk, M - kk, M + kk, kk};
           pn = pre((q * R2 + k) * 4, idc);

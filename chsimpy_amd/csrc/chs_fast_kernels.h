@@ -508,11 +508,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   T* scr = lds + (size_t)sub * C::SCR;
   typename C::V z[C::E];
   if constexpr (DIAG && FUSE) STAMP(0, 0);
-  recombine<C, false, true, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
-                            [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool, NoFetch) {
-    T y[4];
-    row_load<C>(T2, row, pbase, l, idx, y);
-    Ya = cx_make(y[0], y[1]); Yb = cx_make(y[2], y[3]);
+  // (the loads are the slot's fetch: issued in the slot on the large grids, all up front on the small ones -- PreAll)
+  struct RowQuad { T y[4]; };
+  recombine<C, false, true, false>(z, tb, l, [&](int pbase, const int* idx) {
+    RowQuad p;
+    row_load<C>(T2, row, pbase, l, idx, p.y);
+    return p;
+  }, [&](int, const int*, Cx<T>& Ya, Cx<T>& Yb, bool, const RowQuad& p) {
+    Ya = cx_make(p.y[0], p.y[1]); Yb = cx_make(p.y[2], p.y[3]);
   }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
   inv_passes<C, RTW>(z, scr, tbp, launder(l));
