@@ -11,7 +11,11 @@ def _fingerprint(u):
     """Two reductions over the field (~10 ms at N=4096, paid only after a download of 128 MB): enough to notice
     any edit in place short of one constructed to preserve both."""
     a = np.asarray(u)
-    return (a.shape, float(a.sum()), float(np.vdot(a, a)))
+    # (einsum, not vdot: a BLAS call would wake a thread pool sized for every core of the host; inside a container
+    # with a CPU quota its spinning workers use the quota up and the whole process -- the thread that issues the next
+    # run's kernel launches included -- is throttled for the rest of the scheduler period: the reference's default run
+    # repeated in one process took 97 instead of 35 ms, tools/probe_default.py)
+    return (a.shape, float(a.sum()), float(np.einsum('ij,ij->', a, a)) if a.ndim == 2 else float(np.einsum('i,i->', a.ravel(), a.ravel())))
 
 
 class Solution:
