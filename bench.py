@@ -294,6 +294,8 @@ def main():
         a.gpus = world
     dist = None
     import torch
+    torch.set_num_threads(1)  # collectives on a few scalars: no intra-op pool (a pool sized for every core of the host, spinning
+                              # inside a CPU quota, throttles the thread that issues the kernel launches -- DESIGN.md section 9)
     # one process per GPU over RCCL (backend "nccl"); CHS_DIST_BACKEND=gloo + CHS_BENCH_SAME_GPU=1 lets the
     # N>1 logic be rehearsed with several ranks on a single-GPU box (collectives on CPU tensors)
     backend = os.environ.get('CHS_DIST_BACKEND', 'nccl')
