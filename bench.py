@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=0, help='0 = size the CPU sample automatically')
     ap.add_argument('--profile-steps', type=int, default=20)
+    ap.add_argument('--no-extras', action='store_true', help='skip the two extra figures a default --gpus 1 line carries under '
+                    'config (full_call_5000_ms_per_step, cfg3_n8192_f32_adaptive_steps_per_s): A/B scripts')
     ap.add_argument('--energy-stop', action='store_true', help='full_sim=False (the reference default: stop at the E2 maximum); not the headline workload')
     ap.add_argument('--continue-loop', action='store_true', help='the timed call continues the device loop of the warm-up call '
                     '(hat_U carried, last call of the run) instead of entering through hat_U = dctn(U) as every '
@@ -125,6 +127,44 @@ def cpu_baseline(N, steps_hint):
             'sample': f'oracle/chs_oracle.py (numpy+scipy.fftpack), N={N} fp64, {steps} timesteps after prepare() per run, '
                       f'1 warm-up + {len(times)} timed runs (mean {mean:.1f} s, min {min(times):.1f} s), BLAS limited to 1 thread; '
                       f'host has {os.cpu_count()} logical cores'}
+
+
+def extra_figures(a, eng, torch, device):
+    """Two claims of DESIGN.md section 7 measured inside the driver's own run, behind the
+    timed region and the profile leg, each a few hundred ms:
+    * full_call_5000_ms_per_step -- BASELINE.json configs[2] as ONE literal solve_or_resume call of 5000 steps (ntmax),
+      hat_U = dctn(U) on entry, U stored at the end, on the engine the headline was timed on;
+    * cfg3_n8192_f32_adaptive_steps_per_s -- BASELINE.json configs[3]: N=8192, fp32, adaptive_time on; the adaptive
+      branch is live beyond step 500 (solver.py:177), so 520 untimed steps, then one 600-step call."""
+    import chsimpy_amd
+    out = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows, rc = eng.step_n(5000, rederive_hat=True, last_call=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rc == 0 and rows.shape[0] == 5000:
+        out['full_call_5000_ms_per_step'] = round(dt * 1e3 / 5000, 5)
+        out['full_call_5000_steps_per_s'] = round(5000 / dt, 1)
+    p = chsimpy_amd.Parameters()
+    p.N, p.ntmax, p.full_sim, p.kappa_tilde = 8192, 10 ** 9, True, KAPPA
+    p.dtype, p.engine, p.device, p.adaptive_time, p.delt_max = 'float32', 'fast', device, True, 6e-11
+    s3 = chsimpy_amd.Solver(p)
+    try:
+        s3.prepare()
+        e3 = s3._engine
+        r0, rc0 = e3.step_n(519)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r1, rc1 = e3.step_n(600)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rc0 == 0 and rc1 == 0 and r1.shape[0] == 600 and r1[-1, 8] > r1[0, 8]:   # the step size did adapt
+            out['cfg3_n8192_f32_adaptive_steps_per_s'] = round(600 / dt, 1)
+            out['cfg3_n8192_f32_adaptive_ms_per_step'] = round(dt * 1e3 / 600, 5)
+    finally:
+        s3.close(fetch_U=False)
+    return out
 
 
 def ensemble_baseline(a):
@@ -210,7 +250,8 @@ def dry_run(a, rank, world, dist, coll_dev):
         print(json.dumps({'metric': metric_name(a.grid, a.dtype), 'value': None, 'unit': 'timesteps/s', 'n_gpus': world,
                           'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': None, 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'data': 'dry-run (launcher rehearsal, no device work: not a measurement)',
-                          'energies_last_step': energies}), flush=True)
+                          'energies_last_step': energies,
+                          'host_cores_per_rank': len(os.sched_getaffinity(0)) if world > 1 else None}), flush=True)
 
 
 def metric_name(N, dtype):
@@ -222,59 +263,17 @@ def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, one process
     per GPU, like the reference's ensemble starts its own worker pool (chsimpy/experiment.py:197-216).
     This parent has not touched the GPU (no torch.cuda, no engine): the ranks are ordinary child
-    processes (never an exec of a process that has initialised the device).  Rank 0's JSON line is
-    forwarded; any failing rank fails the run."""
-    import socket
-    import subprocess
+    processes (never an exec of a process that has initialised the device; chsimpy_amd/launch.py).  Rank 0's JSON
+    line is forwarded; any failing rank fails the run."""
     import __graft_entry__ as g
+    from chsimpy_amd import launch
     if not a.dry_run:
         g.build_hip()  # once, before the ranks start (hipcc only; no device needed)
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    import tempfile
-    procs, outs = [], []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        outs.append(tempfile.TemporaryFile(mode='w+'))  # every rank's stdout is kept (a file: no pipe to fill up)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=outs[-1], text=True))
-    # Poll all ranks: the first one to fail ends the run (its siblings would otherwise sit in the rendezvous or a
-    # barrier until the collective's own timeout), and the whole launch is bounded.
-    deadline = time.time() + float(os.environ.get('CHS_BENCH_LAUNCH_TIMEOUT', '1500'))
-    failed = None
-    while failed is None and any(p.poll() is None for p in procs):
-        bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
-        if bad:
-            failed = f'rank {bad[0]} exited with {procs[bad[0]].returncode}'
-        elif time.time() > deadline:
-            failed = 'timeout'
-        else:
-            time.sleep(0.05)
-    if failed is not None:
-        for p in procs:          # our own children, by handle
-            if p.poll() is None:
-                p.terminate()
-        for p in procs:
-            try:
-                p.wait(timeout=10)
-            except subprocess.TimeoutExpired:
-                p.kill()
-                p.wait()
-    codes = [p.returncode for p in procs]
-    texts = []
-    for f in outs:
-        f.seek(0)
-        texts.append(f.read())
-        f.close()
+    failed, codes, texts = launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus,
+                                              timeout_s=float(os.environ.get('CHS_BENCH_LAUNCH_TIMEOUT', '1500')))
     line = [ln for ln in texts[0].splitlines() if ln.startswith('{')]
-    if failed is not None or any(codes) or not line:
-        sys.stderr.write(f'bench.py: {failed or "a rank failed"}; ranks exited with {codes}\n')
-        for r, t in enumerate(texts):
-            if t:
-                sys.stderr.write(f'--- stdout of rank {r} ---\n{t}')
+    if failed is not None or not line:
+        launch.report_failure('bench.py', failed or 'rank 0 printed no result line', codes, texts)
         sys.exit(1)
     print(line[-1], flush=True)
 
@@ -293,9 +292,12 @@ def main():
     if world != a.gpus and world > 1:
         a.gpus = world
     dist = None
+    # every rank keeps to its own share of the host cores, decided before anything touches the GPU (chsimpy_amd/launch.py)
+    from chsimpy_amd import launch
+    pinned = launch.pin_rank_to_cores(local_rank, world)
     import torch
-    torch.set_num_threads(1)  # collectives on a few scalars: no intra-op pool (a pool sized for every core of the host, spinning
-                              # inside a CPU quota, throttles the thread that issues the kernel launches -- DESIGN.md section 9)
+    launch.quiet_host_threads()  # collectives on a few scalars: no intra-op pool (a pool sized for every core of the host, spinning
+                                 # inside a CPU quota, throttles the thread that issues the kernel launches -- DESIGN.md section 9)
     # one process per GPU over RCCL (backend "nccl"); CHS_DIST_BACKEND=gloo + CHS_BENCH_SAME_GPU=1 lets the
     # N>1 logic be rehearsed with several ranks on a single-GPU box (collectives on CPU tensors)
     backend = os.environ.get('CHS_DIST_BACKEND', 'nccl')
@@ -433,6 +435,7 @@ def main():
                                    f'kappa_tilde={KAPPA}, ' + ('energy stop armed (full_sim=False)' if a.energy_stop else 'full_sim'),
                        'N': N, 'engine': eng.engine,
                        'ensemble': f'{world} independent run(s), one per GPU' if world > 1 else 'single run',
+                       'host_cores_per_rank': None if pinned is None else len(pinned),
                        'device_ms_per_step': round(dev_ms / a.steps, 5),
                        'untimed_steps_before_timed_region': max(a.warmup, PREWARM),
                        'call_entry': 'continues the device loop of the warm-up call (hat_U resident, last call of the run)'
@@ -443,6 +446,8 @@ def main():
             'roofline': roofline,
             'energies_last_step': energies,
         }
+        if world == 1 and not a.no_extras and N == 4096 and esz == 8 and not a.energy_stop and eng.engine == 'fast':
+            out['config'].update(extra_figures(a, eng, torch, device))
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(N, a.cpu_steps)
         elif world == 1:

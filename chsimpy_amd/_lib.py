@@ -56,19 +56,53 @@ class EngineError(RuntimeError):
 _lib = None
 
 
+def resolve_library():
+    """The library to load and whether it is the product.  CHS_LIB_PATH selects another build (an experiment
+    variant under lib/variants/, tools/ab.sh) -- said aloud on stderr, never silently.  The product library
+    (lib/libchs_hip.so) must carry the sha256 of the sources in the tree (chsimpy_amd/_build.py): one that does
+    not -- a variant copied over it, a library older than an edit -- is rebuilt when hipcc is at hand and refused
+    otherwise (CHS_NO_REBUILD=1: always refused)."""
+    import sys
+    from . import _build
+    override = os.environ.get('CHS_LIB_PATH')
+    if override:
+        have, flags = _build.embedded_provenance(override)
+        sys.stderr.write(f"chsimpy_amd: CHS_LIB_PATH -> {override} (sources {str(have)[:12]}, extra flags '{flags}'): "
+                         "NOT the product library\n")
+        return override, False
+    path = LIB_PATH
+    want = _build.source_hash()
+    if want is None or not os.path.exists(path):
+        return path, True        # no sources to check against (an installed copy) / missing: load() reports it
+    have, flags = _build.embedded_provenance(path)
+    if have == want and not flags:
+        return path, True
+    what = (f"{path} was built from other sources than the tree holds (library {str(have)[:12]}, tree {want[:12]}"
+            + (f", extra flags '{flags}'" if flags else '') + ")")
+    if os.environ.get('CHS_NO_REBUILD') == '1':
+        raise EngineError(what + "; rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    try:
+        _build.build_hip()
+    except Exception as e:
+        raise EngineError(what + f"; rebuilding it failed: {e}") from e
+    return path, True
+
+
 def load():
-    """Load the HIP library once; raise if it (or any declared symbol) is missing."""
+    """Load the HIP library once; raise if it (or any declared symbol) is missing or it is not built from the
+    sources in the tree."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path, _product = resolve_library()
+    if not os.path.exists(path):
         raise EngineError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). chsimpy_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for s in SYMBOLS:
         if not hasattr(lib, s):
-            raise EngineError(f"{LIB_PATH} does not export `{s}` (declared in include/chs_hip.h)")
+            raise EngineError(f"{path} does not export `{s}` (declared in include/chs_hip.h)")
     dp = C.POINTER(C.c_double)
     lib.chs_create.argtypes = [C.POINTER(chs_consts), dp, C.POINTER(C.c_void_p)]
     lib.chs_destroy.argtypes = [C.c_void_p]

@@ -20,7 +20,12 @@ int chs_hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return CHS_EHIP;
 }
 extern "C" const char* chs_last_error(void) { return g_err.c_str(); }
-extern "C" const char* chs_version(void) { return "chsimpy_amd 0.1 (gfx950)"; }
+// what this library was built from: sha256 of csrc/* + include/* and the extra flags of the build (chsimpy_amd/_build.py
+// passes -DCHS_PROVENANCE; the loader compares it with the tree, chsimpy_amd/_lib.py)
+#ifndef CHS_PROVENANCE
+#define CHS_PROVENANCE "CHS_SRC_HASH=unknown;CHS_FLAGS=;"
+#endif
+extern "C" const char* chs_version(void) { return "chsimpy_amd 0.4 (gfx950) " CHS_PROVENANCE; }
 
 // ---------------------------------------------------------------------------
 // kernel-slot timing (chs_profile_steps)
@@ -497,10 +502,12 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   if (nsteps < 0) nsteps = 0;
   CHS_HIP(hipSetDevice(E->hc.device));
   E->stateCached = false;
+#if CHS_TEST_HOOKS
   {
     const char* gw = getenv("CHS_TEST_GATE_WITHHOLD");  // test hook: provoke the gate's timeout path
     E->testGateWithhold = gw && gw[0] == '1';
   }
+#endif
   int rc;
   if ((rc = ensure_rows(E))) return rc;
   if (profile) {
@@ -582,9 +589,12 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   if (s.gate_timeout) {
     // A workgroup gave up waiting for the riding bookkeeping (never seen outside the test hook): the call's
     // remaining kernels were no-ops, the loop's device state is not that of a completed step.  The handle stays
-    // usable: the next call enters through hat_U = dctn(U) of whatever field it is given (chs_set_U / chs_prepare).
+    // usable, but only through a new field: the fused row kernel has not been storing U and the counters have
+    // advanced by the steps that did finish, so nothing on the device is a consistent state to step on from --
+    // the next chs_step_n returns CHS_ESTATE until chs_set_U / chs_init_U_pcg64 and chs_prepare have run.
     E->hat_valid = false; E->resident = false; E->stateCached = false;
     E->tailDeferred = false; E->tailGated = false;
+    E->prepared = false; E->have_U = false;
     if (steps_done) *steps_done = 0;
     chs_set_error("internal: a workgroup gave up waiting for the step's bookkeeping (gated tail)");
     return CHS_EHIP;

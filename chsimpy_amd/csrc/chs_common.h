@@ -202,7 +202,7 @@ struct Engine {
   bool tailDeferred = false;  // the tail of the previous step is still to run
   bool tailGated = false;     // ... and the other workgroups of that k_col wait for its decision (stop rules, adaptive dt)
   unsigned long long gateSeq = 0;
-  bool testGateWithhold = false;  // test hook (CHS_TEST_GATE_WITHHOLD=1 at chs_create): gated tails never publish
+  bool testGateWithhold = false;  // test hook (CHS_TEST_GATE_WITHHOLD=1, read by chs_step_n in builds with -DCHS_TEST_HOOKS=1): gated tails never publish
   bool preRider = false;      // the first step's time-step control rides in its k_col (deferred-tail mode)
   unsigned stepCount = 0;     // k_col<MODE_STEP> launches so far (tile walk direction alternates)
   // jitter noise generated on the device: numpy's PCG64 stream continued from the host generator's state

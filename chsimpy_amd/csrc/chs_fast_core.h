@@ -2,7 +2,8 @@
 //
 // One length-N orthonormal DCT-II (scipy.fftpack.dct(type=2, norm='ortho'), the 1-D
 // factor of the dctn calls at chsimpy/solver.py:159,201) is computed by a GROUP of G
-// lanes (G <= 64, so a group never spans wavefronts) as
+// lanes (G <= 64: inside one wavefront, exchanges behind wavefront fences; G = 128 / 256 at N >= 4096: two or four
+// wavefronts of one workgroup, exchanges behind the workgroup barrier -- FCfg::WAVE_LOCAL, xsync) as
 //     Makhoul reordering + packing  z[n] = v[2n] + i v[2n+1]        (implicit in the loads)
 //  -> M = N/2 point complex FFT, decimation in frequency, 2 or 3 register-resident
 //     radix passes with the operands exchanged through a group-private LDS scratch

@@ -258,11 +258,9 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
 // a workgroup that gives up raises gate_timeout AND halt, so that every later kernel of the call is a no-op
 // and the call ends with an error instead of stepping on with a column pass that did not happen.
 // Ordering (MI355X_MICROARCH.md, inter-workgroup visibility): the producer wrote the state with plain stores,
-// drained them, released at agent scope and then stored the sequence number.  The consumer's polling lane reads
-// the payload itself, after its poll has matched, with agent-scope loads that bypass this CU's L1 (sc1) -- the
-// measured-valid form that spares the L1 invalidate an acquire fence would cost the co-resident workgroup; the
-// compiler barrier keeps those loads behind the poll in program order (a wavefront's loads return in order).
-// The other wavefronts get the values through LDS behind the workgroup barrier.  `box` = 4 doubles of LDS.
+// drained them, released at agent scope and then stored the sequence number.  The consumer's polling lane polls
+// relaxed, issues ONE agent-scope acquire once the poll has matched and then reads the payload itself (agent-scope
+// loads); the other wavefronts get the values through LDS behind the workgroup barrier.  `box` = 4 doubles of LDS.
 __device__ __forceinline__ int gate_wait(DevState* __restrict__ st, unsigned long long seq, int spins, double* box,
                                          double& lam1, double& lam2) {
   if (threadIdx.x == 0) {
@@ -277,7 +275,10 @@ __device__ __forceinline__ int gate_wait(DevState* __restrict__ st, unsigned lon
         break;
       }
     }
-    asm volatile("" ::: "memory");
+    // ONE agent-scope acquire in the polling lane, once per workgroup and step, behind the matched poll: the payload
+    // loads below are ordered behind the poll by the memory model, not by what gfx950 happens to do with sc1 loads
+    // (gated modes only -- stop rules armed or an adaptive step)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int halt = __hip_atomic_load(&st->halt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     box[0] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&st->lam1), __ATOMIC_RELAXED,
                                                                __HIP_MEMORY_SCOPE_AGENT));

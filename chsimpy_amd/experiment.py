@@ -170,6 +170,9 @@ def write_results(file_id, records):
     import pandas as pd
     df = pd.DataFrame(records, columns=COLS)
     df[['tau0', 'id']] = df[['tau0', 'id']].astype(int)
+    # tsep = argmax(E2) is an integer in the reference's tuples (experiment.py:113); after the gather of a float64 block
+    # it must read the same, or the file would depend on the number of ranks
+    df['tsep'] = df['tsep'].astype(int)
     df.to_csv(f"{file_id}-results.csv")
     agg = df.loc[:, df.columns != 'id'].describe()
     agg.loc['cv'] = agg.loc['std'] / agg.loc['mean']
@@ -199,6 +202,39 @@ def run_ensemble(init_params, ep, run_fn=None, U_init=None, dist=None, rank=0, w
     return gather_records(local, nr_items, rank, world, dist, device)
 
 
+def _dry_member(run_id, init_params, rand_values, A_list):
+    """`--dry-run`: a member without device work (launcher / partition / collective rehearsal on CPUs) -- a
+    deterministic function of the run's coefficients, so that the result files can be compared across world sizes."""
+    params, f0, f1 = run_params(init_params, run_id, rand_values, A_list)
+    a0, a1 = params.func_A0(params.temp), params.func_A1(params.temp)
+    return (a0, a1, 0.1, 0.9, 0.2, 0.8, 100 + run_id, 1.5 * run_id, 7 * run_id, run_id,
+            np.nan if f0 is None else f0, np.nan if f1 is None else f1)
+
+
+def _launch_own_ranks(a, argv):
+    """`--gpus G` without a launcher around it: this process -- which has not touched the GPU -- starts the G ranks as
+    ordinary child processes, one per GPU, as the reference starts its own pool (experiment.py:197-216), and forwards
+    rank 0's output."""
+    import sys
+    from . import launch
+    if not a.dry_run:
+        import importlib.util
+        entry = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), '__graft_entry__.py')
+        if os.path.exists(entry):   # build once, before the ranks start (hipcc only; no device needed)
+            spec = importlib.util.spec_from_file_location('__graft_entry__', entry)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.build_hip()
+    args = list(sys.argv[1:] if argv is None else argv)
+    failed, codes, texts = launch.spawn_ranks([sys.executable, '-m', 'chsimpy_amd.experiment'] + args, a.gpus,
+                                              timeout_s=float(os.environ.get('CHS_LAUNCH_TIMEOUT', '86400')))
+    if failed is not None:
+        launch.report_failure('chsimpy_amd.experiment', failed, codes, texts)
+        raise SystemExit(1)
+    sys.stdout.write(texts[0])
+    sys.stdout.flush()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description='chsimpy_amd ensemble (cf. chsimpy-experiment)')
     ap.add_argument('-N', type=int, default=512)
@@ -213,19 +249,36 @@ def main(argv=None):
     ap.add_argument('--export-csv', default=None)
     ap.add_argument('--Uinit-file', default=None)
     ap.add_argument('--concurrent', type=int, default=2, help='ensemble members running at once per GPU')
+    ap.add_argument('--gpus', type=int, default=1, help='start this many ranks (one per GPU) from here when no launcher '
+                    'such as torch.distributed.run has set RANK/WORLD_SIZE')
+    ap.add_argument('--backend', default=os.environ.get('CHS_DIST_BACKEND', 'nccl'),
+                    help='torch.distributed backend: nccl (= RCCL, ranks on GPUs) or gloo (CPU rehearsal)')
+    ap.add_argument('--dry-run', action='store_true', help='members without device work: rehearses launcher, partition, '
+                    'core placement and the gather on CPUs; the result files are not results')
     a = ap.parse_args(argv)
+
+    if a.gpus > 1 and 'RANK' not in os.environ:
+        return _launch_own_ranks(a, argv)
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # Placement first, before anything touches the GPU: this rank's share of the host cores (the reference sizes its
+    # pool to the physical cores, experiment.py:197-202; here the cores are dealt to the ranks), one torch intra-op thread
+    from . import launch
+    pinned = launch.pin_rank_to_cores(local_rank, world)
     dist = None
     device = 'cpu'
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-        device = f'cuda:{local_rank}'
+        launch.quiet_host_threads()
+        if a.backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+            device = f'cuda:{local_rank}'
+        else:
+            dist.init_process_group(backend=a.backend)
 
     p = Parameters()
     p.N, p.ntmax, p.full_sim, p.kappa_tilde = a.N, a.ntmax, a.full_sim, a.kappa_tilde
@@ -237,9 +290,11 @@ def main(argv=None):
     U_init = utils.csv_import_matrix(p.Uinit_file) if p.Uinit_file else None
 
     if rank == 0:
-        write_metadata(p.file_id, ep, extra=[f"ranks, {world}", f"concurrent_per_rank, {a.concurrent}"])
-    records = run_ensemble(p, ep, U_init=U_init, dist=dist, rank=rank, world=world, device=device,
-                           concurrent=a.concurrent)
+        write_metadata(p.file_id, ep, extra=[f"ranks, {world}", f"concurrent_per_rank, {a.concurrent}",
+                                             f"host_cores_per_rank, {'all' if pinned is None else len(pinned)}"]
+                       + (["dry_run, True"] if a.dry_run else []))
+    records = run_ensemble(p, ep, run_fn=_dry_member if a.dry_run else None, U_init=U_init, dist=dist, rank=rank,
+                           world=world, device=device, concurrent=a.concurrent)
     if rank == 0:
         df, agg = write_results(p.file_id, records)
         print(agg.T)

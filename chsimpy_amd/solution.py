@@ -18,6 +18,13 @@ def _fingerprint(u):
     return (a.shape, float(a.sum()), float(np.einsum('ij,ij->', a, a)) if a.ndim == 2 else float(np.einsum('i,i->', a.ravel(), a.ravel())))
 
 
+def _same_print(p, q):
+    """Fingerprints equal, a NaN sum equal to a NaN sum (a field holding NaN must not look edited forever)."""
+    if p[0] != q[0]:
+        return False
+    return all(x == y or (x != x and y != y) for x, y in zip(p[1:], q[1:]))
+
+
 class Solution:
     def __init__(self, params=None):
         p = self.params = params
@@ -71,7 +78,7 @@ class Solution:
     def _host_edited(self):
         """True when the host mirror of the device field has been changed in place since it was downloaded."""
         u, fp = self.__dict__.get('_U'), self.__dict__.get('_U_print')
-        return u is not None and fp is not None and _fingerprint(u) != fp
+        return u is not None and fp is not None and not _same_print(_fingerprint(u), fp)
 
     @U.setter
     def U(self, value):
@@ -82,11 +89,13 @@ class Solution:
         self.__dict__['_U_print'] = None
         self.__dict__['_U_dirty'] = value is not None
 
-    def _bind_device_U(self, host_copy=None, fetch=None):
-        """The engine's own field: `host_copy` mirrors it already, or `fetch()` downloads it on demand."""
+    def _bind_device_U(self, host_copy=None, fetch=None, track=True):
+        """The engine's own field: `host_copy` mirrors it already, or `fetch()` downloads it on demand.  A host mirror
+        is fingerprinted like a downloaded one (`track`), so that `sol.U[i, j] = x` between prepare() and the first
+        solve_or_resume -- the reference starts from that very array, solver.py:158 -- is noticed too."""
         self.__dict__['_U'] = host_copy
         self.__dict__['_U_fetch'] = fetch
-        self.__dict__['_U_print'] = None
+        self.__dict__['_U_print'] = _fingerprint(host_copy) if (track and host_copy is not None) else None
         self.__dict__['_U_dirty'] = False
 
     def __getstate__(self):

@@ -140,7 +140,7 @@ class Solver:
             else:
                 # the caller needs scalars only: solution.U stays what the host already has (None when
                 # the field was never downloaded)
-                self.solution._bind_device_U(self.solution.__dict__.get('_U'))
+                self.solution._bind_device_U(self.solution.__dict__.get('_U'), track=False)
             self._engine.close()
             self._engine = None
 
@@ -230,7 +230,7 @@ class Solver:
             if rows.shape[0] > 1:
                 sol.timedata.extend(rows[:-1])
             self._pull_state()
-            sol._bind_device_U(self._engine.get_U())
+            sol._bind_device_U(self._engine.get_U(), track=False)
             # the reference fails the same way: assert in TimeData.insert (timedata.py:10)
             raise AssertionError("NaN in a recorded scalar (U left (0,1)) at step %d" % sol.computed_steps)
         if rows.shape[0]:

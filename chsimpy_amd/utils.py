@@ -117,16 +117,6 @@ def get_system_info():
     return info
 
 
-def get_int_max_value():
-    return np.iinfo(np.intp).max
-
-
-def sec_to_min_if(value, t=60):
-    if value > t:
-        return str(round(value / 60.0, 1)) + 'min'
-    return str(round(value, 1)) + 's'
-
-
 # -- thermodynamic helpers (sympy; utils.py:143-180) ---------------------------
 
 def _energy_expr(sym, c, R, T, B, A0_, A1_):

@@ -105,8 +105,10 @@ typedef struct chs_handle_s* chs_handle;
  * a new one.  The parked engines hold at most 3 GiB of device memory together (the least recently parked
  * ones are freed first); chs_pool_clear() frees them all.  CHS_ENGINE_POOL=0 (read at both calls) switches
  * the pool off.  A handle must not be used after chs_destroy either way.
- * CHS_TEST_GATE_WITHHOLD=1 (test hook, read by chs_step_n): the in-launch bookkeeping of stop-rule / adaptive runs never publishes
- * its decision, so that the waiting workgroups run into their bounded timeout -> chs_step_n returns CHS_EHIP. */
+ * CHS_TEST_GATE_WITHHOLD=1 (test hook, read by chs_step_n; compiled in only when the library is built with
+ * -DCHS_TEST_HOOKS=1, which __graft_entry__.build() does -- a build without it ignores the variable): the in-launch
+ * bookkeeping of stop-rule / adaptive runs never publishes its decision, so that the waiting workgroups run into
+ * their bounded timeout -> chs_step_n returns CHS_EHIP. */
 int chs_create(const chs_consts* consts, const double* lambda, chs_handle* out);
 int chs_destroy(chs_handle h);
 /* Free every parked engine of this process (all devices); chs_pool_count: how many are parked right now. */
@@ -149,7 +151,11 @@ int chs_prepare(chs_handle h, double row0[9]);
  * observe it; chs_get_U after the call returns the field of the last completed step
  * in every mode -- also after an energy or time-limit stop, where it is rebuilt from
  * hat_U -- exactly as `self.solution.U = U` after the reference's loop
- * (solver.py:197-199, 242-251). */
+ * (solver.py:197-199, 242-251).
+ * CHS_EHIP with "gave up waiting" (the bounded wait of the in-launch bookkeeping ran out; only ever seen with
+ * the test hook): *steps_done = 0 and the device holds no consistent state of a completed step -- the handle
+ * is un-prepared and field-less afterwards: chs_step_n returns CHS_ESTATE until chs_set_U / chs_init_U_pcg64
+ * and chs_prepare have been called again. */
 int chs_step_n(chs_handle h, int64_t nsteps, int32_t flags, double* rows, int64_t* steps_done);
 /* flags for chs_step_n */
 #define CHS_STEP_CARRY_HAT 1 /* do not re-derive hat_U on entry: continue the loop of the

@@ -169,3 +169,88 @@ def test_postprocessing_errors_are_raised_not_swallowed(monkeypatch, tmp_path):
         ex.run_experiment_gpu(0, p, rv, al)
     rec = ex.run_experiment_gpu(0, p, rv, al, postprocess=False)   # explicit opt-out: NaN columns
     assert np.isnan(rec[2]) and rec[8] == 1 and rec[6] == 3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# world size 8 (the node the ensemble is meant for: one rank per MI355X), rehearsed on CPUs with gloo
+# ---------------------------------------------------------------------------------------------------------------
+def _worker8(rank, world, port, outdir):
+    """One rendezvous, three ensembles: BASELINE.json configs[4]'s 64 runs, an uneven count (61: the last round of the
+    deal is short, the gather block is padded) and --independent (2 x 32 items)."""
+    import torch.distributed as dist
+    from chsimpy_amd import launch
+    pinned = launch.pin_rank_to_cores(rank, world)       # before anything else, as experiment.main does
+    launch.quiet_host_threads()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    p = chsimpy_amd.Parameters()
+    p.N, p.kappa_tilde, p.file_id = 16, 3e-4, 'ens'
+    for name, runs, indep in (('c64', 64, False), ('c61', 61, False), ('ind', 32, True)):
+        ep = ex.ExperimentParams()
+        ep.runs, ep.independent = runs, indep
+        recs = ex.run_ensemble(p, ep, run_fn=_fake_run, dist=dist, rank=rank, world=world)
+        np.save(os.path.join(outdir, f'{name}_rank{rank}.npy'), np.array(recs, dtype=np.float64))
+    np.save(os.path.join(outdir, f'cores_rank{rank}.npy'), np.array(sorted(pinned) if pinned else [-1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world8_deals_64_61_and_independent_runs(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    p = chsimpy_amd.Parameters()
+    p.N, p.kappa_tilde, p.file_id = 16, 3e-4, 'ens'
+    for name, runs, indep, items in (('c64', 64, False, 64), ('c61', 61, False, 61), ('ind', 32, True, 64)):
+        ep = ex.ExperimentParams()
+        ep.runs, ep.independent = runs, indep
+        single = np.array(ex.run_ensemble(p, ep, run_fn=_fake_run), dtype=np.float64)
+        assert single.shape == (items, 12)
+        for r in range(8):                                  # every rank holds every record, ordered by run id
+            got = np.load(str(tmp_path / f'{name}_rank{r}.npy'))
+            assert got.shape == single.shape and np.array_equal(got, single, equal_nan=True), (name, r)
+        assert list(single[:, 9]) == list(range(items))
+    # --independent: the first half varies A0 only, the second A1 only (experiment.py:163-170)
+    ind = np.load(str(tmp_path / 'ind_rank0.npy'))
+    assert np.all(ind[:32, 11] == 1.0) and np.all(ind[32:, 10] == 1.0) and not np.any(ind[:32, 10] == 1.0)
+    # core placement: the ranks' core sets are disjoint slices of what this process may use (when there are >= 8)
+    sets = [set(np.load(str(tmp_path / f'cores_rank{r}.npy')).tolist()) for r in range(8)]
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) >= 8:
+        assert all(s and -1 not in s for s in sets)
+        assert sum(len(s) for s in sets) == len(set().union(*sets)) == len(allowed)
+    assert sorted(os.sched_getaffinity(0)) == allowed      # the parent's own affinity is untouched
+
+
+def test_core_slices():
+    from chsimpy_amd import launch
+    assert launch.core_slices(range(16), 8) == [[2 * r, 2 * r + 1] for r in range(8)]
+    assert launch.core_slices(range(8), 3) == [[0, 1, 2], [3, 4, 5], [6, 7]]
+    assert launch.core_slices([4, 9], 4) == [[4], [9], [4], [9]]        # fewer cores than ranks: shared
+    assert launch.core_slices([], 2) == [[], []]
+    assert launch.pin_rank_to_cores(0, 1) is None                       # one rank: nothing to deal
+
+
+def test_experiment_starts_its_own_8_ranks_and_the_files_do_not_depend_on_the_world_size(tmp_path):
+    """`python -m chsimpy_amd.experiment --gpus 8` without a launcher around it (a parent that never touches the GPU
+    starts the ranks, as chsimpy/experiment.py:197-216 starts its pool), `--dry-run --backend gloo` standing in for
+    the device work: 61 runs over 8 ranks give the result files of a single rank."""
+    import subprocess
+    import pandas as pd
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e['PYTHONPATH'] = ROOT + os.pathsep + e.get('PYTHONPATH', '')
+    base = ['-N', '16', '-K', '3e-4', '-R', '61', '--dry-run', '--backend', 'gloo']
+    r8 = subprocess.run([sys.executable, '-m', 'chsimpy_amd.experiment', '--gpus', '8', '--file-id', str(tmp_path / 'w8')] + base,
+                        env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    r1 = subprocess.run([sys.executable, '-m', 'chsimpy_amd.experiment', '--file-id', str(tmp_path / 'w1')] + base,
+                        env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    a, b = pd.read_csv(str(tmp_path / 'w8-results.csv'), index_col=0), pd.read_csv(str(tmp_path / 'w1-results.csv'), index_col=0)
+    assert a.shape == (61, 12) and a.equals(b)
+    assert open(str(tmp_path / 'w8-results-agg.csv')).read() == open(str(tmp_path / 'w1-results-agg.csv')).read()
+    meta = open(str(tmp_path / 'w8-metadata.csv')).read()
+    assert 'ranks, 8' in meta and 'dry_run, True' in meta and 'host_cores_per_rank' in meta
+    assert 'Output files:' in r8.stdout            # rank 0's report is forwarded by the launching parent

@@ -528,8 +528,86 @@ def test_fp32_n8192_adaptive_steps_vs_oracle_seeded_at_step_499(gpu):
              f"E2 {errs[2]:.3e} Ra {errs[5]:.3e} L2 {errs[6]:.3e} PS {errs[7]:.3e} U {relerr(U, o.U):.3e}")
     assert errs[8] < 1e-4, errs                                # the delt history (solver.py:183-188)
     assert errs[1] < 1e-5 and errs[7] < 2e-3, errs             # E, PS
+    # E2 (a difference quotient of an fp32 field), Ra (one row's mean absolute deviation) and L2 = ||mu||/N^2 in fp32
+    # against the fp64 oracle -- measured 1.1e-4 / 4.0e-5 / 7.9e-6 (profiles/r03_parity_margins.txt); stated
+    # tolerances a factor ~5-10 above that
+    assert errs[2] < 1e-3 and errs[5] < 4e-4 and errs[6] < 1e-4, errs
     assert np.allclose(rows[:, 4], to[:, 4], rtol=1e-4)        # domtime = (sum delt / M_tilde)^(1/3)
     assert np.allclose(U, o.U, rtol=2e-4, atol=0), relerr(U, o.U)
+    s.close(fetch_U=False)
+
+
+def test_n4096_gated_stop_path_vs_oracle_time_limit_with_energy_rule_armed(gpu):
+    """The reference's default mode (full_sim=False, parameters.py:50) plus a time limit (solver.py:197-199) at the
+    HEADLINE size.  At N >= 4096 the stop rules do not use the two-buffer hat_U of the small grids but the gate:
+    the bookkeeping of step s rides in k_col(s+1), whose tile workgroups wait for its decision in front of their
+    first write (gate_wait); a stop leaves hat_U as step s left it and run_steps rebuilds U = idctn(hat_U)
+    (chs_fast_recover_u) -- a code path no test below N=4096 runs.  time_max is chosen so that the limit ends the
+    run after 8 completed steps (about 1.4 s per oracle step on one core).  Chunks: 3 and 3 steps through the gate
+    without a stop, then a call of 10 that the limit ends after 2 (gate -> halt -> rebuilt U), then a resumed
+    call that completes nothing but still advances time_delta_sum by one delt (solver.py:195 runs before the
+    check).  U, the record, counters and time bookkeeping against the oracle after every call, rtol 1e-9."""
+    N = 4096
+    tmax = 8.5 * 3e-8 / 1.71e-8 / 60          # minutes of simulated time = 8.5 steps
+    kw = dict(full_sim=False, time_max=tmax)
+    s = chsimpy_amd.Solver(make(N, 10 ** 6, 'fast', **kw))
+    s.rederive_hat = True                      # the literal solver.py:159 at every call, as the oracle does
+    o = orc.OracleSolver(orc.make_params(N, 10 ** 6, **kw))
+    s.prepare(); o.prepare()
+    expect = {4: (4, 'None'), 3: (7, 'None'), 10: (9, 'time-limit'), 2: (9, 'time-limit')}
+    for chunk in (4, 3, 10, 2):
+        sol = s.solve_or_resume(chunk)
+        o.solve_or_resume(chunk)
+        assert (sol.computed_steps, sol.stop_reason) == (o.computed_steps, o.stop_reason) == expect[chunk], chunk
+        eu = relerr(sol.U, o.U)
+        log_line(f"N=4096 gated stop path (full_sim=False + time limit), after chunk {chunk}: steps {sol.computed_steps} "
+                 f"stop {sol.stop_reason} U {eu:.3e}")
+        assert eu < RTOL, (chunk, eu)
+        assert s.time_delta_sum == pytest.approx(o.time_delta_sum, rel=1e-13)
+        assert s.time_passed == pytest.approx(o.time_passed, rel=1e-13)
+    td, to = sol.timedata.data(), o.timedata.data()
+    assert td.shape == to.shape == (9, 9)
+    for c in range(1, 9):
+        assert np.allclose(td[:, c], to[:, c], rtol=RTOL, atol=1e-300), (c, relerr(td[:, c], to[:, c]))
+    assert sol.tau0 == o.tau0 and sol.t0 == o.t0
+    s.close(fetch_U=False)
+
+
+def test_n4096_fp64_adaptive_steps_vs_oracle_seeded_at_step_499(gpu):
+    """adaptive_time (solver.py:177-193) in fp64 at the headline size against the ORACLE: the branch fires beyond
+    step 500 only, and 500 oracle steps at N=4096 take twelve minutes -- so both codes are seeded at
+    computed_steps = 499 from the same start field (chs_set_state / the oracle's attribute), as the N=8192 fp32 test
+    does, and run 8 steps: records 499..506, delt re-evaluated at steps 502, 504, 506 from the fused row kernel's
+    column partials, the two-stage reduction, lam1/lam2 regenerated on the device behind the gate.
+    delt / E / E2 / U at rtol 1e-9."""
+    N, steps, dmax = 4096, 8, 1.2e-10
+    kw = dict(adaptive_time=True, delt_max=dmax)
+    s = chsimpy_amd.Solver(make(N, 10 ** 6, 'fast', **kw))
+    s.prepare()
+    eng = s._engine
+    st = eng.get_state()
+    st.computed_steps = 499
+    st.skip_check = 1          # (the energy rule indexes the record by step number, timedata.py:63: not with a seeded counter)
+    eng.set_state(st)
+    rows, rc = eng.step_n(steps)
+    assert rc == 0 and rows.shape == (steps, 9)
+    U = eng.get_U()
+    o = orc.OracleSolver(orc.make_params(N, 10 ** 6, **kw))
+    o.prepare()
+    o.computed_steps = 499
+    o.skip_check = True
+    o.solve_or_resume(steps)
+    to = o.timedata.data()[1:]
+    assert np.array_equal(rows[:, 0], to[:, 0]) and rows[0, 0] == 499 and rows[-1, 0] == 506
+    assert len(np.unique(to[:, 8])) == 4                       # delt: the seed value, then three re-evaluations
+    assert to[-1, 8] > 2.0 * to[0, 8]                          # ... that did move it
+    errs = {c: relerr(rows[:, c], to[:, c]) for c in (1, 2, 4, 5, 6, 7, 8)}
+    eu = relerr(U, o.U)
+    log_line(f"N=4096 fp64 adaptive, seeded at step 499, 8 steps vs oracle: delt {errs[8]:.3e} E {errs[1]:.3e} "
+             f"E2 {errs[2]:.3e} Ra {errs[5]:.3e} L2 {errs[6]:.3e} PS {errs[7]:.3e} U {eu:.3e}")
+    for c in (1, 2, 4, 5, 6, 7, 8):
+        assert errs[c] < RTOL, errs
+    assert eu < RTOL, eu
     s.close(fetch_U=False)
 
 

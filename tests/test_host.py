@@ -218,3 +218,91 @@ def test_in_place_edit_of_a_downloaded_field_is_noticed():
     assert not sol._host_edited()
     sol.U = dev                            # assignment takes the other road (dirty flag)
     assert sol.__dict__['_U_dirty'] and not sol._host_edited()
+
+
+def test_edit_of_a_host_mirror_between_prepare_and_solve_is_noticed():
+    """prepare() with a host U_init binds that array as the mirror of the device field (`_bind_device_U(host_copy)`):
+    an edit in place before the first solve_or_resume is what the reference would start from (solver.py:158), so it
+    must be noticed as well; a field holding NaN must not look edited forever (NaN-safe comparison)."""
+    p = chsimpy_amd.Parameters()
+    p.N, p.kappa_tilde = 16, 0.0002989112919661156
+    sol = chsimpy_amd.Solution(p)
+    host = np.full((16, 16), 0.875)
+    sol._bind_device_U(host)
+    assert not sol._host_edited()
+    host[2, 3] = 0.9
+    assert sol._host_edited()
+    bad = np.full((16, 16), 0.875)
+    bad[0, 0] = np.nan
+    sol._bind_device_U(bad)
+    assert not sol._host_edited()          # NaN == NaN for this purpose
+    sol._bind_device_U(host, track=False)  # close(fetch_U=False): nothing to compare afterwards
+    assert sol.__dict__['_U_print'] is None
+
+
+def test_download_path_never_enters_blas(monkeypatch):
+    """Round 3's host-side trap: a BLAS call (np.vdot) in the download path woke a thread pool sized for every core of
+    the host, which used up the container's CPU quota and throttled the NEXT run's kernel launches.  The mechanism, not
+    the pace, is asserted: with numpy's BLAS-backed entry points booby-trapped, fingerprinting, the lazy download and
+    the in-place-edit check still run."""
+    def boom(*a, **k):
+        raise AssertionError("BLAS entry point called from the download path")
+    for name in ('dot', 'vdot', 'inner', 'matmul', 'tensordot'):
+        monkeypatch.setattr(np, name, boom)
+    monkeypatch.setattr(np.linalg, 'norm', boom)
+    from chsimpy_amd import solution
+    p = chsimpy_amd.Parameters()
+    p.N, p.kappa_tilde = 64, 0.0002989112919661156
+    sol = chsimpy_amd.Solution(p)
+    dev = np.random.default_rng(1).random((64, 64))
+    sol._bind_device_U(None, lambda: dev.copy())
+    u = sol.U
+    assert not sol._host_edited()
+    u[0, 0] += 1.0
+    assert sol._host_edited()
+    assert solution._fingerprint(dev.ravel())[0] == (4096,)
+    # np.einsum('ij,ij->') must not route through BLAS either (it does only with optimize=True / tensordot paths)
+    import inspect
+    assert 'optimize' not in inspect.getsource(solution._fingerprint)
+
+
+def test_a_stale_or_foreign_library_is_refused(tmp_path, monkeypatch, hip_lib):
+    """Build provenance (chsimpy_amd/_build.py): the product library carries the sha256 of the sources it was built
+    from.  A library whose hash is not the tree's -- an experiment variant copied over lib/libchs_hip.so, a build
+    older than an edit -- is refused by the loader (CHS_NO_REBUILD=1; without it the loader rebuilds), whatever its
+    modification time says; the real library passes; CHS_LIB_PATH loads a variant only when told to, aloud."""
+    from chsimpy_amd import _build
+    assert _build.is_current(_lib.LIB_PATH)
+    have, flags = _build.embedded_provenance(_lib.LIB_PATH)
+    assert have == _build.source_hash() and flags == ''
+    assert have in _lib.load().chs_version().decode()          # chs_version() reports it
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    # (a) a library built from other sources: same file, another hash -- and NEWER than every source
+    stale = tmp_path / 'libchs_hip.so'
+    other = ('0' * 64).encode()
+    stale.write_bytes(blob.replace(have.encode(), other))
+    assert not _build.is_current(str(stale))
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(stale))
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setenv('CHS_NO_REBUILD', '1')
+    monkeypatch.delenv('CHS_LIB_PATH', raising=False)
+    with pytest.raises(_lib.EngineError, match='built from other sources'):
+        _lib.load()
+    # (b) the right sources but experiment flags (a variant left behind as the product)
+    variant = tmp_path / 'variant.so'
+    variant.write_bytes(blob.replace(b'CHS_FLAGS=;', b'CHS_FLAGS=-DX;', 1))
+    assert _build.embedded_provenance(str(variant)) == (have, '-DX')
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(variant))
+    with pytest.raises(_lib.EngineError, match="extra flags '-DX'"):
+        _lib.load()
+    # (c) without CHS_NO_REBUILD the loader rebuilds instead of loading it
+    called = []
+    monkeypatch.delenv('CHS_NO_REBUILD')
+    monkeypatch.setattr(_build, 'build_hip', lambda *a, **k: called.append(1) or (_ for _ in ()).throw(RuntimeError('no hipcc here')))
+    with pytest.raises(_lib.EngineError, match='rebuilding it failed'):
+        _lib.load()
+    assert called
+    # (d) an explicit CHS_LIB_PATH is honoured and announced
+    monkeypatch.setenv('CHS_LIB_PATH', str(variant))
+    path, product = _lib.resolve_library()
+    assert path == str(variant) and product is False

@@ -1,7 +1,8 @@
 #!/bin/bash
 # A/B timing of prebuilt library variants on one GPU box (box-to-box clocks differ by a few %):
 #   tools/ab.sh [rounds] [bench args...]  -- runs bench.py with every chsimpy_amd/lib/variants/*.so, interleaved
-#   (AB_GLOB='[ab]_*' restricts the variants)
+#   (AB_GLOB='[ab]_*' restricts the variants).  The variants are selected through CHS_LIB_PATH; the product library
+#   is never overwritten (an interrupted A/B cannot leave a variant behind as the product).
 rounds=${1:-2}
 shift
 args=${@:---steps 300 --warmup 300}
@@ -9,8 +10,7 @@ mkdir -p gpurun_out
 : > gpurun_out/ab.log
 for r in $(seq $rounds); do
   for v in chsimpy_amd/lib/variants/${AB_GLOB:-*}.so; do
-    cp $v chsimpy_amd/lib/libchs_hip.so
-    timeout -k 10 200 python bench.py --no-cpu-baseline $args > gpurun_out/ab_one.log 2>&1 || { echo "$v failed"; tail -3 gpurun_out/ab_one.log; continue; }
+    CHS_LIB_PATH=$PWD/$v timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras $args > gpurun_out/ab_one.log 2>gpurun_out/ab_one.err || { echo "$v failed"; tail -3 gpurun_out/ab_one.err; continue; }
     python - "$v" <<'PY' | tee -a gpurun_out/ab.log
 import json, sys
 d = json.loads(open('gpurun_out/ab_one.log').read().strip().splitlines()[-1])

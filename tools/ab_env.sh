@@ -10,7 +10,7 @@ mkdir -p gpurun_out
 : > gpurun_out/ab_env.log
 for r in $(seq $rounds); do
   for s in "${sets[@]}"; do
-    env $s timeout -k 10 300 python bench.py --no-cpu-baseline $args > gpurun_out/ab_one.log 2> gpurun_out/ab_one.err || { echo "[$s] failed"; tail -3 gpurun_out/ab_one.err; continue; }
+    env $s timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras $args > gpurun_out/ab_one.log 2> gpurun_out/ab_one.err || { echo "[$s] failed"; tail -3 gpurun_out/ab_one.err; continue; }
     python - "$s" <<'PY' | tee -a gpurun_out/ab_env.log
 import json, sys
 d = json.loads(open('gpurun_out/ab_one.log').read().strip().splitlines()[-1])

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Build a library variant for tools/ab.sh: tools/build_variant.sh <name> "<extra hipcc flags>"
-# (the default build is left in place afterwards)
+# The variant goes to chsimpy_amd/lib/variants/<name>.so (objects cached per variant); the product library
+# chsimpy_amd/lib/libchs_hip.so is never touched.  A variant is selected through CHS_LIB_PATH.
 set -e
 name=$1; flags=$2
-mkdir -p chsimpy_amd/lib/variants
-cp chsimpy_amd/lib/libchs_hip.so /tmp/libchs_default.so 2>/dev/null || true
-CHS_EXTRA_FLAGS="$flags" python -c "import __graft_entry__ as g; g.build_hip(force=True)"
-cp chsimpy_amd/lib/libchs_hip.so chsimpy_amd/lib/variants/$name.so
-if [ -f /tmp/libchs_default.so ]; then cp /tmp/libchs_default.so chsimpy_amd/lib/libchs_hip.so; touch chsimpy_amd/lib/libchs_hip.so; fi
-echo "built variants/$name.so"
+python - "$name" "$flags" <<'PY'
+import sys
+sys.path.insert(0, '.')
+from chsimpy_amd import _build
+out = _build.build_hip(out=f"{_build.LIBDIR}/variants/{sys.argv[1]}.so", extra=sys.argv[2])
+print("built", out, _build.embedded_provenance(out))
+PY
