@@ -159,9 +159,14 @@ def extra_figures(a, eng, torch, device):
         r1, rc1 = e3.step_n(600)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if rc0 == 0 and rc1 == 0 and r1.shape[0] == 600 and r1[-1, 8] > r1[0, 8]:   # the step size did adapt
+        # (the adaptive branch runs on every second step of the window; by step 520 the step size has left params.delt)
+        if rc0 == 0 and rc1 == 0 and r1.shape[0] == 600 and r1[-1, 8] > 1.5 * p.delt:
             out['cfg3_n8192_f32_adaptive_steps_per_s'] = round(600 / dt, 1)
             out['cfg3_n8192_f32_adaptive_ms_per_step'] = round(dt * 1e3 / 600, 5)
+            out['cfg3_delt_first_last'] = [float(r1[0, 8]), float(r1[-1, 8])]
+        else:
+            out['cfg3_n8192_f32_adaptive_steps_per_s'] = None
+            out['cfg3_note'] = f'not measured: rc {rc0}/{rc1}, rows {r1.shape[0]}, delt {float(r1[0, 8]) if r1.shape[0] else None}'
     finally:
         s3.close(fetch_U=False)
     return out

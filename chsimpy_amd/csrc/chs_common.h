@@ -99,6 +99,70 @@ __device__ __forceinline__ double block_min(double v, double* scratch) {
   return t;
 }
 
+// Wavefront and lane number WITHOUT keeping threadIdx.x alive in a VGPR across a register-heavy kernel.  A kernel at its
+// register limit spills such a long-lived index, and a 4-byte spill reload sits in the in-order vmcnt queue behind every
+// store issued before it.  The wavefront's number goes to an SGPR once; the lane number is two v_mbcnt wherever it is
+// needed (volatile: never carried from one use to the next either).  One-dimensional blocks of whole wavefronts only.
+__device__ __forceinline__ int chs_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int chs_lane_id() {
+  int x;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+  __builtin_assume(x >= 0 && x < 64);
+  return x;
+}
+// wave_sum with the lane number taken afresh: __shfl_down computes its own lane number with a pure builtin, which the
+// compiler hoists out of loops and keeps (or spills) like any other loop invariant.  Same tree, same sums in lane 0.
+__device__ __forceinline__ double wave_sum_fresh(double v) {
+  const int ln = chs_lane_id();
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int src = ((ln + off) & 63) << 2;
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src, (int)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(src, (int)(b >> 32));
+    v += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  }
+  return v;  // valid in lane 0
+}
+// block_sum with the caller's wavefront number (SGPR) instead of threadIdx.x
+__device__ __forceinline__ double block_sum_w(double v, double* scratch, int wave, int nw) {
+  v = wave_sum_fresh(v);
+  __syncthreads();
+  if (chs_lane_id() == 0) scratch[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < nw; ++w) t += scratch[w];
+  return t;
+}
+// block_sum_store in two halves: `begin` right where the values are complete (wavefront sums into `red`: no register
+// holds them any longer -- in the fused row kernel that is five accumulators less across the whole forward transform),
+// `end` behind a barrier at the end of the kernel (wavefront 0's lane 0 adds up and gets out[]; returns true there).
+template <int NV, bool FRESH = true>
+__device__ __forceinline__ void block_reduce_begin(const double (&v)[NV], double* red /* >= NW*NV */, int wave) {
+  double w[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) w[i] = FRESH ? wave_sum_fresh(v[i]) : wave_sum(v[i]);
+  if (chs_lane_id() == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * NV + i] = w[i];
+  }
+}
+template <int NV, int NW>
+__device__ __forceinline__ bool block_reduce_end(const double* red, double* __restrict__ out, int wave) {
+  __syncthreads();
+  const bool first = (wave == 0) && (chs_lane_id() == 0);
+  if (first) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double t = red[i];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) t += red[w * NV + i];
+      out[i] = t;
+    }
+  }
+  return first;
+}
+
 // NV per-thread values -> block totals (NW waves per block), left in out[0..NV) of thread 0.
 // One barrier, no loops with run-time trip counts: meant for the END of a register-heavy
 // kernel, where control flow around live register arrays would cost spills.

@@ -201,6 +201,13 @@ int chs_fast_enter_fused(Engine* E) {
   rc = P->row_fwd2(E, E->dU, E->dT2, E->dT1);
   chs_slot_end(E, SLOT_MU);
   if (rc) return rc;
+  // k_col<FWD_NATIVE> writes hat_U tile by tile in ascending order.  The first step's k_col walks the tiles in ASCENDING
+  // order too (0; 1 = descending: what was written last is read first -- measured 2.3 % slower on a literal 20-step call,
+  // profiles/r04_ab_dma.txt), whatever the parity of the steps of earlier calls; then the directions alternate (CHS_COL_ZIGZAG)
+#ifndef CHS_ENTRY_REVERSE
+#define CHS_ENTRY_REVERSE 0
+#endif
+  if (CHS_ENTRY_REVERSE >= 0) E->stepCount = CHS_ENTRY_REVERSE;
   return P->col(E, MODE_FWD_NATIVE, E->dT2, nullptr, E->dHat, nullptr);
 }
 

@@ -73,6 +73,14 @@ using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, CHS_PAD1, CH
 #define CHS_F4096C_TW_LDS 2
 #endif
 template <> struct ColTwLds<F4096C> { static constexpr int value = CHS_F4096C_TW_LDS; };
+// Stage-in by LDS-DMA (round 4; chs_fast_kernels.h: DmaStage) in this one-workgroup-per-item kernel -- every piece of
+// both halves of the tile requested at kernel entry, one wait, no staging registers, 32 ds_write_b64 per thread fewer,
+// parity green -- measured 2.8 % SLOWER per step (k_col +5 %), in-process A/B on one box: 0.2201 against 0.2139 ms
+// (profiles/r04_ab_dma.txt).  Off; kept as a switch.
+#ifndef CHS_F4096C_DMA
+#define CHS_F4096C_DMA 0
+#endif
+template <> struct ColDma<F4096C> { static constexpr bool value = (CHS_F4096C_DMA != 0); };
 
 // fp64 at N = 8192: the shape of the fp32 configuration of that size (four wavefronts per transform,
 // two rows or two of a tile's four columns per 512-thread workgroup)

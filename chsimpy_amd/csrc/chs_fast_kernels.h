@@ -172,16 +172,40 @@ __device__ __forceinline__ int row_of_block(int b) {
 #ifndef CHS_ROW_INTERLEAVE_MIN_N
 #define CHS_ROW_INTERLEAVE_MIN_N 8192
 #endif
+// `wave` = chs_wave_id() (an SGPR), the lane number is taken afresh (chs_lane_id): neither threadIdx.x nor l / sub need to
+// stay in registers between the phases of a row kernel -- they are recomputed by calling this again.  Groups of whole
+// wavefronts without the interleave: sub is wave-uniform (an SGPR, and with it the row number and the scratch base).
 template <class C>
-__device__ __forceinline__ void row_lane_map(int& l, int& sub) {
+__device__ __forceinline__ void row_lane_map(int wave, int& l, int& sub) {
+  const int ln = chs_lane_id();
   if constexpr (C::C == 2 && (C::G % 64 == 0) && C::N >= CHS_ROW_INTERLEAVE_MIN_N) {
-    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
     sub = ln >> 5;
-    l = w * 32 + (ln & 31);
+    l = wave * 32 + (ln & 31);
+  } else if constexpr (C::G % 64 == 0) {
+    constexpr int WG = C::G / 64;   // wavefronts per transform
+    sub = wave / WG;
+    l = (wave % WG) * 64 + ln;
   } else {
-    l = threadIdx.x % C::G;
-    sub = threadIdx.x / C::G;
+    const int tid = wave * 64 + ln;
+    l = tid % C::G;
+    sub = tid / C::G;
   }
+}
+__device__ __forceinline__ int launder(int x);
+// FRESH (fp64, whose row kernels sit at their 128 registers and spilled these indices): lane index and row within the
+// workgroup are recomputed per phase.  Otherwise (fp32: room to spare, the recomputation only adds instructions -- N=8192
+// fp32 measured 1.1 % slower with it) the values taken at the top of the kernel are passed through an opaque copy.
+template <class C>
+struct FreshLane { static constexpr bool value = (sizeof(typename C::T) == 8); };
+template <class C, bool FORCE = false>
+__device__ __forceinline__ int row_l(int wave, int l_top) {
+  if constexpr (FORCE || FreshLane<C>::value) { int l, sub; row_lane_map<C>(wave, l, sub); return l; }
+  else return launder(l_top);
+}
+template <class C, bool FORCE = false>
+__device__ __forceinline__ int row_sub(int wave, int sub_top) {
+  if constexpr (FORCE || FreshLane<C>::value) { int l, sub; row_lane_map<C>(wave, l, sub); return sub; }
+  else return launder(sub_top);
 }
 
 template <typename T>
@@ -268,7 +292,7 @@ constexpr int row_tw_lds_elems() {
 // The row kernels' LDS copy of their pass twiddles (RowTwLds), behind the exchange scratch and the log table; returns the
 // table set to use.  The caller provides the barrier between the copy and the first use.
 template <class C>
-__device__ __forceinline__ FTables<typename C::T> row_twiddles_to_lds(const FTables<typename C::T>& tb) {
+__device__ __forceinline__ FTables<typename C::T> row_twiddles_to_lds(const FTables<typename C::T>& tb, int tid) {
   using T = typename C::T;
   constexpr int RTWM = RowTwLds<C>::value;
   FTables<T> tbp = tb;
@@ -276,7 +300,7 @@ __device__ __forceinline__ FTables<typename C::T> row_twiddles_to_lds(const FTab
     T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16);
     constexpr int N0 = (RTWM == 2) ? 2 * C::L1 : (RTWM == 1 ? 2 * (C::R0 - 1) * C::L1 : 0), NM = row_tw_lds_elems<C>() - N0;
     auto cp = [&](T* dst, const T* src, int n) {
-      for (int i = 2 * threadIdx.x; i < n; i += 2 * C::THREADS) {
+      for (int i = 2 * tid; i < n; i += 2 * C::THREADS) {
         if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst + i) = *reinterpret_cast<const double2*>(src + i);
         else *reinterpret_cast<v2f*>(dst + i) = *reinterpret_cast<const v2f*>(src + i);
       }
@@ -314,12 +338,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
   __shared__ double red[32];
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
+  const int wv = chs_wave_id();   // (threadIdx.x is not kept: chs_common.h)
   int l, sub;
-  row_lane_map<C>(l, sub);
+  row_lane_map<C>(wv, l, sub);
   const int row = row_of_block<C>(blockIdx.x) + sub;
   T* scr = lds + (size_t)sub * C::SCR;
   constexpr int RTWM = RowTwLds<C>::value;
-  const FTables<T> tbp = row_twiddles_to_lds<C>(tb);
+  const FTables<T> tbp = row_twiddles_to_lds<C>(tb, wv * 64 + chs_lane_id());
   if constexpr (RTWM != 0) __syncthreads();
   typename C::V z[C::E];
   double s2 = 0.0;
@@ -341,7 +366,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
     // no division, no spills at four waves per SIMD; the division-based chs_mu needed 204 bytes of scratch here)
     double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
     if constexpr (sizeof(T) == 8) {
-      for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
+      for (int t = wv * 64 + chs_lane_id(); t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
       __syncthreads();
     }
     unsigned dom = 0;
@@ -360,18 +385,25 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
       z[e] = cx_make(a, b);
     }
     if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of this step becomes NaN
+    // (the wavefront sums go to LDS here: no register carries the sum across the transform)
+    const double acc1[1] = {s2};
+    block_reduce_begin<1, FreshLane<C>::value>(acc1, red, wv);
   }
-  fwd_passes<C, (RTWM == 2)>(z, scr, tbp, l);
-  recombine<C, true, false, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },
+  fwd_passes<C, (RTWM == 2)>(z, scr, tbp, row_l<C>(wv, l));
+  // (lane index and row of the last phase: taken afresh here, laundered per slot -- address arithmetic is redone at the
+  // point of use instead of being computed for all slots up front and kept in registers)
+  const int lr = row_l<C>(wv, l), sr = row_sub<C>(wv, sub);
+  const int rw = row_of_block<C>(blockIdx.x) + sr;
+  recombine<C, true, false, false>(z, tb, lr, [](int, const int*) { return NoFetch{}; },
                             [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
     if (live) {
       const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
-      row_store<C>(T1, row, pbase, l, idx, y);
+      row_store<C>(T1, rw, pbase, launder(lr), idx, y);
     }
   }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (POINTWISE) {
-    const double tot = block_sum(s2, red);
-    if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
+    double tot[1];
+    if (block_reduce_end<1, C::THREADS / 64>(red, tot, wv)) partMu[blockIdx.x] = tot[0];
   }
 }
 
@@ -393,28 +425,26 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
   __shared__ double red[32];
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
+  const int wv = chs_wave_id();   // (threadIdx.x is not kept: chs_common.h; lane index, row and scratch base are taken
+                                  // afresh in every phase instead of living -- or being spilled -- across the passes)
   int l, sub;
-  row_lane_map<C>(l, sub);
-  const int row = row_of_block<C>(blockIdx.x) + sub;
-  T* scr = lds + (size_t)sub * C::SCR;
+  row_lane_map<C>(wv, l, sub);
   double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
   if constexpr (sizeof(T) == 8) {
-    for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
+    for (int t = wv * 64 + chs_lane_id(); t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
   }
   // pass twiddles from LDS where the configuration has room (RowTwLds, as in the fused row kernel: at N=8192 fp32,
   // 30 twiddle loads per radix-16 butterfly, this kernel took 511 us with them in L2)
   constexpr int RTWM = RowTwLds<C>::value;
   constexpr bool RTW = (RTWM == 2);
-  const FTables<T> tbp = row_twiddles_to_lds<C>(tb);
+  const FTables<T> tbp = row_twiddles_to_lds<C>(tb, wv * 64 + chs_lane_id());
   if constexpr (sizeof(T) == 8 || RTWM != 0) __syncthreads();  // the log table and the twiddles are visible
   typename C::V z[C::E];
-  double s2 = 0.0;
-  unsigned dom = 0;
   const T RT = (T)dc.RT, BRT = (T)dc.BRT, A0 = (T)dc.A0, A1 = (T)dc.A1;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    const int lp = launder(l);
-    const unsigned urow = (unsigned)launder(row) * C::N;
+    const int lp = row_l<C, true>(wv, l);
+    const unsigned urow = (unsigned)(row_of_block<C>(blockIdx.x) + row_sub<C, true>(wv, sub)) * C::N;
 #pragma unroll
     for (int q = 0; q < C::NP0; ++q) {
       const int m1 = lp + C::G * q, m2 = C::L1 - 1 - m1;
@@ -432,6 +462,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
       }
     }
     if (pass == 1) {
+      // (the sum lives in this branch only: its wavefront sums go to LDS in front of the transform, so that no register
+      // carries it through the passes -- or, where the two passes stay a rolled loop, around the loop)
+      double s2 = 0.0;
+      unsigned dom = 0;
       auto mu = [&](T& u) {
         const T uinv = T(1) - u;
         const T lU = chs_log_unit_tab<T>(u, ltab, dom), lV = chs_log_unit_tab<T>(uinv, ltab, dom);
@@ -447,23 +481,30 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
         z[e] = cx_make(a, b);
       }
       if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of the first step becomes NaN
+      const double acc1[1] = {s2};
+      block_reduce_begin<1, true>(acc1, red, wv);
     }
     T* dst = pass ? T1 : Ta;
-    fwd_passes<C, RTW>(z, scr, tbp, launder(l));
-    recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
+    {
+      const int lf = row_l<C, true>(wv, l), sf = row_sub<C, true>(wv, sub);
+      fwd_passes<C, RTW>(z, lds + (size_t)sf * C::SCR, tbp, lf);
+    }
+    const int lr = row_l<C, true>(wv, l), sr = row_sub<C, true>(wv, sub);
+    const int rw = row_of_block<C>(blockIdx.x) + sr;
+    recombine<C, true, false, false>(z, tb, lr, [](int, const int*) { return NoFetch{}; },
                               [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
       if (live) {
         const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
         // Ta is read once, by k_col<FWD_NATIVE> right behind this kernel: streamed like U (driver protocol 4471 -> 4533
         // steps/s, profiles/r03_ab_nt.txt); T1 is the first step's operand and stays cached
-        if (pass == 0) row_store<C, true>(dst, launder(row), pbase, launder(l), idx, y);
-        else row_store<C>(dst, launder(row), pbase, launder(l), idx, y);
+        if (pass == 0) row_store<C, true>(dst, rw, pbase, launder(lr), idx, y);
+        else row_store<C>(dst, rw, pbase, launder(lr), idx, y);
       }
     }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
     __builtin_amdgcn_sched_barrier(0);
   }
-  const double tot = block_sum(s2, red);
-  if (threadIdx.x == 0) partMu[blockIdx.x] = tot;
+  double tot[1];
+  if (block_reduce_end<1, C::THREADS / 64>(red, tot, wv)) partMu[blockIdx.x] = tot[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -487,19 +528,20 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   __shared__ double red[64];
   if (st->halt) return;
   T* lds = reinterpret_cast<T*>(chs_dyn_lds);
+  const int wv = chs_wave_id();   // (threadIdx.x is not kept across the kernel: chs_common.h)
   int l, sub;
-  row_lane_map<C>(l, sub);
+  row_lane_map<C>(wv, l, sub);
   const double mean_u = st->meanU;  // requested at entry (k_col of this step wrote it), used in the pointwise part
   // reduction table of the table-driven log, behind the exchange scratch (visible after the first barrier)
   double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
   if constexpr (DIAG && sizeof(T) == 8) {
-    for (int t = threadIdx.x; t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
+    for (int t = wv * 64 + chs_lane_id(); t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
   }
   // pass twiddles from LDS where the configuration has room (RowTwLds): visible behind the first exchange barrier of
   // the inverse passes, whose last-pass butterflies come first and need none
   constexpr int RTWM = RowTwLds<C>::value;
   constexpr bool RTW = (RTWM == 2);   // pass-0 twiddles by powers
-  const FTables<T> tbp = row_twiddles_to_lds<C>(tb);
+  const FTables<T> tbp = row_twiddles_to_lds<C>(tb, wv * 64 + chs_lane_id());
   // (groups inside one wavefront exchange behind wavefront fences only: no block barrier would make the log table and
   // the twiddles visible before their first use)
   if constexpr (C::WAVE_LOCAL && ((DIAG && sizeof(T) == 8) || RTWM != 0)) __syncthreads();
@@ -510,7 +552,12 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   if constexpr (DIAG && FUSE) STAMP(0, 0);
   // (the loads are the slot's fetch: issued in the slot on the large grids, all up front on the small ones -- PreAll)
   struct RowQuad { T y[4]; };
-  recombine<C, false, true, false>(z, tb, l, [&](int pbase, const int* idx) {
+  // (!FUSE: the lane index goes in through an opaque copy -- the once-per-call kernels otherwise keep a multiple of it
+  // alive from the log-table copy at the top and spill it; the fused kernel's code is left as it is)
+#ifndef CHS_ROW_IN_PIPE
+#define CHS_ROW_IN_PIPE 0
+#endif
+  recombine<C, false, true, (CHS_ROW_IN_PIPE != 0)>(z, tb, FUSE ? l : fc_opaque(l), [&](int pbase, const int* idx) {
     RowQuad p;
     row_load<C>(T2, row, pbase, l, idx, p.y);
     return p;
@@ -518,13 +565,12 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     Ya = cx_make(p.y[0], p.y[1]); Yb = cx_make(p.y[2], p.y[3]);
   }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
-  inv_passes<C, RTW>(z, scr, tbp, launder(l));
+  inv_passes<C, RTW>(z, scr, tbp, row_l<C>(wv, l));
   if constexpr (DIAG && FUSE) STAMP(0, 2);
   __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
   const unsigned urow = (unsigned)row * C::N;
   double sEdge = 0.0;
-  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  const int ls = launder(l);
+  const int ls = row_l<C>(wv, l);
   // FUSE: between the steps of one call nothing reads U from HBM (the next step continues from the
   // registers) except the tail's np.gradient row-edge terms, which look at rows 0, 1, N-2, N-1: with
   // store_u == 0 only the workgroups owning those rows write them (chs_fast_step decides).
@@ -570,20 +616,20 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     const bool ra_blk = (row0 == (RR / C::C) * C::C);
     if (ra_blk) {
       // Ra: mean absolute deviation of one row from its own mean (two passes over registers)
-      const bool mine = ra_blk && sub == RR % C::C;
+      const bool mine = ra_blk && row_sub<C>(wv, sub) == RR % C::C;
       double rs = 0.0;
       if (mine) {
 #pragma unroll
         for (int e = 0; e < C::E; ++e) rs += (double)cx_re(z[e]) + (double)cx_im(z[e]);
       }
-      const double rmean = block_sum(rs, red) / (double)C::N;
+      const double rmean = block_sum_w(rs, red, wv, C::THREADS / 64) / (double)C::N;
       double ad = 0.0;
       if (mine) {
 #pragma unroll
         for (int e = 0; e < C::E; ++e) ad += fabs((double)cx_re(z[e]) - rmean) + fabs((double)cx_im(z[e]) - rmean);
       }
-      const double ra = block_sum(ad, red) / (double)C::N;
-      if (ra_blk && threadIdx.x == 0) partRa[0] = ra;
+      const double ra = block_sum_w(ad, red, wv, C::THREADS / 64) / (double)C::N;
+      if (ra_blk && wv == 0 && chs_lane_id() == 0) partRa[0] = ra;
       __syncthreads();
     }
     const T RT = (T)dc.RT, BRT = (T)dc.BRT, B = (T)dc.B, A0 = (T)dc.A0, A1 = (T)dc.A1;
@@ -621,7 +667,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       __builtin_amdgcn_sched_barrier(0);
     }
     if (dom > (unsigned)(CHS_LOGTAB_N - 1)) sE = __builtin_nan("");  // U left (0,1): the record of this step becomes NaN
-    acc[0] = sE; acc[1] = sEdge; acc[2] = sPS; acc[3] = (double)cSA; acc[4] = s2;
+    // The five sums leave the registers HERE (wavefront sums into `red`), not at the end of the kernel: carried across the
+    // forward transform they were what the register allocator spilled (and a spill reload waits behind every T1 store).
+    const double acc[5] = {sE, sEdge, sPS, (double)cSA, s2};
+    block_reduce_begin<5, FreshLane<C>::value>(acc, red, wv);
   }
   if constexpr (ADAPT) {
     // Adaptive step (solver.py:177-183): on the steps whose successor re-evaluates delt, the column
@@ -638,7 +687,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
                   "partial column sums need the scratch");
     const long long cs = st->computed_steps + 1;  // the record of this step has not advanced it yet
     if (cs > 500 && (cs % 2) == 0) {              // (uniform) cf. k_mu's want_col
-      const int lg = launder(l);
+      const int lg = row_l<C>(wv, l);
+      const int sub_a = row_sub<C>(wv, sub);
       T* prow = partColRows + (size_t)blockIdx.x * C::N;
       T* gl = reinterpret_cast<T*>(chs_dyn_lds);
       const T dmax = (T)dc.delt_max;
@@ -647,7 +697,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
 #pragma unroll
         for (int s = C::C - 1; s >= 0; --s) {
           __syncthreads();
-          if (sub == s) {
+          if (sub_a == s) {
 #pragma unroll
             for (int q = 0; q < C::NP0; ++q) {
               const int m1 = lg + C::G * q, m2 = C::L1 - 1 - m1;
@@ -684,24 +734,30 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   if constexpr (DIAG && FUSE) STAMP(0, 4);
   if constexpr (FUSE) {
     __builtin_amdgcn_sched_barrier(0);
-    fwd_passes<C, RTW>(z, scr, tbp, launder(l));
+    T* scr_f = reinterpret_cast<T*>(chs_dyn_lds) + (size_t)row_sub<C>(wv, sub) * C::SCR;
+    fwd_passes<C, RTW>(z, scr_f, tbp, row_l<C>(wv, l));
     if constexpr (DIAG && FUSE) STAMP(0, 5);
     __builtin_amdgcn_sched_barrier(0);
-    recombine<C, true, false, false>(z, tb, launder(l), [](int, const int*) { return NoFetch{}; },
+    const int lr = row_l<C>(wv, l), sr = row_sub<C>(wv, sub);
+    const int rw = row_of_block<C>(blockIdx.x) + sr;
+#ifndef CHS_ROW_OUT_PIPE
+#define CHS_ROW_OUT_PIPE 0
+#endif
+    // (CHS_ROW_OUT_PIPE: the twiddles of slot k+1 requested in front of slot k's T1 stores, as k_col's spectral stage does)
+    recombine<C, true, false, (CHS_ROW_OUT_PIPE != 0)>(z, tb, lr, [](int, const int*) { return NoFetch{}; },
                               [](int, const int*, Cx<T>&, Cx<T>&, bool, NoFetch) {},
                               [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live) {
       if (live) {
         const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
-        row_store<C>(T1, row, pbase, launder(l), idx, y);
+        row_store<C>(T1, rw, pbase, launder(lr), idx, y);
       }
     });
   }
   if constexpr (DIAG && FUSE) STAMP(0, 6);
   if constexpr (DIAG) {
-    // reductions last: the transform registers are dead by now
+    // the wavefront sums have been in `red` since the pointwise part: one barrier, one thread adds them up
     double out5[5];
-    block_sum_store<5, C::THREADS / 64>(acc, red, out5);
-    if (threadIdx.x == 0) {
+    if (block_reduce_end<5, C::THREADS / 64>(red, out5, wv)) {
       double* p = partDiag + (size_t)blockIdx.x * 4;
       p[0] = out5[0]; p[1] = out5[1]; p[2] = out5[2]; p[3] = out5[3];
       if (FUSE) partMu[blockIdx.x] = out5[4];
@@ -717,6 +773,44 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
 // by Parseval this is the interior part of np.gradient's sum of squares (solver.py:
 // 213-217) -- see DESIGN.md section "E2 from the spectrum".
 // ---------------------------------------------------------------------------
+// ---- LDS-DMA stage-in (ColDma): the tile rows go from L2 straight into LDS (global_load_lds_dwordx4: no staging
+// registers, no ds_write), every piece of both halves requested at kernel entry, ONE wait.
+// byte address of an LDS object inside the workgroup's allocation (what DS instructions and M0 take)
+__device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+// one LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to 1 KiB of LDS at `lds_dst` (wave-uniform).
+// M0 carries the destination; it is compiler-reserved, hence saved and restored inside the statement
+// (cdna_hip_programming.md, inline-assembly rules).
+template <bool NT>
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// which configurations stage in by LDS-DMA (chs_fast_f64.hip)
+template <class C>
+struct ColDma { static constexpr bool value = false; };
+// Landing-zone image of one half of the tile (N/2 rows): one 16-byte unit per tile row (the workgroup's 2 columns).  A DMA
+// piece writes 1 KiB linearly -- lane i's 16 bytes at base + 16 i -- so the bank spread that the padded image of the
+// register path gets from its pitch comes from permuting the rows INSIDE each quad on the SOURCE side: unit 4m + (e ^
+// ((m >> 2) & 3)) holds row 4m + e.  The lanes of a piece still fetch the same 16 lines (coalescing unchanged); the quad
+// reads are 2-way conflicted at worst (lanes i and i+16: 32 lanes x 8 bytes out of 16-byte units reach half the banks).
+template <class C>
+struct DmaStage {
+  static constexpr int ROWS = C::N / 2;
+  static constexpr int NW = C::THREADS / 64;
+  static constexpr int NDMA = ROWS / (64 * NW);   // pieces per wavefront and half
+  static constexpr int ZONE = ROWS * C::C;         // elements of a landing zone
+  static constexpr bool OK = (C::C * sizeof(typename C::T) == 16) && (C::G % 64 == 0) && (ROWS % (64 * NW) == 0) && (C::R0 >= 4);
+  static __device__ __forceinline__ int row_of_unit(int p) { const int mq = p >> 2; return 4 * mq + ((p & 3) ^ ((mq >> 2) & 3)); }
+  static __device__ __forceinline__ int unit_of(int mm, int e) { return 4 * mm + (e ^ ((mm >> 2) & 3)); }
+};
+
 template <class C>
 struct ColStage {
   // A workgroup stages C of the CT columns of a tile: per row a piece of C elements at offset
@@ -757,7 +851,9 @@ constexpr int col_tw_lds_elems() {
 
 template <class C>
 constexpr int col_lds_elems() {
-  return (C::C * C::SCR > ColStage<C>::ELEMS) ? C::C * C::SCR : ColStage<C>::ELEMS;
+  constexpr int base = (C::C * C::SCR > ColStage<C>::ELEMS) ? C::C * C::SCR : ColStage<C>::ELEMS;
+  // (LDS-DMA stage-in: the two landing zones, which the exchange scratch and the stage-out image then reuse)
+  return (ColDma<C>::value && 2 * DmaStage<C>::ZONE > base) ? 2 * DmaStage<C>::ZONE : base;
 }
 
 template <class C, int MODE>
@@ -822,7 +918,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   // wait behind the hat_U stores at the start of the inverse passes
   FTables<T> tbp = tb;
   constexpr bool TW0POW = (MODE == MODE_STEP) && (ColTwLds<C>::value == 2);
-  if constexpr (MODE == MODE_STEP && ColTwLds<C>::value != 0) {
+  constexpr bool DMA = ColDma<C>::value && (MODE == MODE_STEP || MODE == MODE_FWD_NATIVE);
+  static_assert(!DMA || (DmaStage<C>::OK && sizeof(T) == 8), "LDS-DMA stage-in: 16-byte row pieces of whole wavefronts");
+  // (DMA: the twiddle copy is requested in front of the DMA pieces and stored behind their wait, below)
+  if constexpr (MODE == MODE_STEP && ColTwLds<C>::value != 0 && !DMA) {
     T* ltw = lds + col_lds_elems<C>();
     // pass-0 part (the whole table, or its k = 1 entries), then twa | twb (contiguous behind tw0 in the table buffer)
     constexpr int N0 = TW0POW ? 2 * C::L1 : 2 * (C::R0 - 1) * C::L1;
@@ -877,7 +976,91 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     p.h23 = ldc_hint<T, HAT_NT_LD>(hcol, hp + C::G);
     return p;
   };
-  if constexpr (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE) {
+  if constexpr (DMA) {
+    // ---- stage in by LDS-DMA: all pieces of both halves of the tile (NDMA per wavefront and half) are requested here,
+    // in front of them the (compiler-visible) loads of the pass twiddles; one wait covers everything (vector-memory
+    // operations complete in order), then the twiddles go to LDS, one barrier, and every lane reads its quads.
+    using DS = DmaStage<C>;
+    constexpr bool TWL = (MODE == MODE_STEP && ColTwLds<C>::value != 0);
+    constexpr int N0 = TW0POW ? 2 * C::L1 : 2 * (C::R0 - 1) * C::L1;
+    constexpr int NM = col_tw_lds_elems<C>() - N0;
+    constexpr int TWI0 = (N0 + 2 * C::THREADS - 1) / (2 * C::THREADS), TWIM = (NM + 2 * C::THREADS - 1) / (2 * C::THREADS);
+    [[maybe_unused]] double2 tw_a[TWL ? TWI0 : 1], tw_b[TWL ? TWIM : 1];
+    T* ltw = lds + col_lds_elems<C>();
+    if constexpr (TWL) {
+#pragma unroll
+      for (int i = 0; i < TWI0; ++i) {
+        const int e = 2 * ((int)threadIdx.x + i * C::THREADS);
+        if (e < N0) tw_a[i] = *reinterpret_cast<const double2*>(tb.tw0 + e);
+      }
+#pragma unroll
+      for (int i = 0; i < TWIM; ++i) {
+        const int e = 2 * ((int)threadIdx.x + i * C::THREADS);
+        if (e < NM) tw_b[i] = *reinterpret_cast<const double2*>(tb.twa + e);
+      }
+      tbp.tw0 = ltw;
+      tbp.twa = ltw + N0;
+      tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
+    }
+    {
+      const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+      const T* tile = Tin + (size_t)ct * C::N * C::CT + hh * C::C;
+      const unsigned base = lds_byte_addr(lds);
+      constexpr bool NT = (MODE == MODE_FWD_NATIVE);  // the entry's intermediate (k_row_fwd2's Ta): its only read
+#pragma unroll
+      for (int rho = 0; rho < 2; ++rho) {
+#pragma unroll
+        for (int i = 0; i < DS::NDMA; ++i) {
+          const int piece = i * DS::NW + wave;
+          const int row = rho * DS::ROWS + DS::row_of_unit(piece * 64 + lane);
+          glds16<NT>(tile + (size_t)row * C::CT,
+                     __builtin_amdgcn_readfirstlane(base + (unsigned)((rho * DS::ZONE) * sizeof(T)) + piece * 1024));
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (TWL) {
+#pragma unroll
+      for (int i = 0; i < TWI0; ++i) {
+        const int e = 2 * ((int)threadIdx.x + i * C::THREADS);
+        if (e < N0) *reinterpret_cast<double2*>(ltw + e) = tw_a[i];
+      }
+#pragma unroll
+      for (int i = 0; i < TWIM; ++i) {
+        const int e = 2 * ((int)threadIdx.x + i * C::THREADS);
+        if (e < NM) *reinterpret_cast<double2*>(ltw + N0 + e) = tw_b[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rho = 0; rho < 2; ++rho) {
+      const T* zone = lds + rho * DS::ZONE;
+#pragma unroll
+      for (int q = 0; q < C::NP0; ++q) {
+        const int m1 = l + C::G * q, m2 = C::L1 - 1 - m1;
+#pragma unroll
+        for (int jj = 0; jj < CS::JR; ++jj) {
+          const int j = rho * CS::JR + jj;
+          T q1[4], q2[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            q1[e] = zone[DS::unit_of(m1 + C::L1 * jj, e) * C::C + sub];
+            q2[e] = zone[DS::unit_of(m2 + C::L1 * jj, e) * C::C + sub];
+          }
+          pack_quads<C>(q1, q2, q, j, z);
+        }
+      }
+    }
+    __syncthreads();   // the landing zones become the exchange scratch
+    if constexpr (MODE == MODE_STEP) STAMP(1, 1);
+    fwd_passes<C, TW0POW>(z, scr, tbp, l);
+    if constexpr (MODE == MODE_STEP) STAMP(1, 2);
+    if constexpr (MODE == MODE_STEP) {
+      if (ta.gate) {  // (the gated tail: see the register-staged path below)
+        if (gate_wait(st, ta.seq, ta.gate_spins, red, lam1, lam2)) return;
+      }
+    }
+  } else if constexpr (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE) {
     // ---- stage in: tile rows -> quads of this group's column.  The first half is requested at once, the
     // second as soon as the first has left its registers (its latency runs under the first half's barrier
     // and quad reads); both pass through LDS half by half.
@@ -956,7 +1139,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
 
   // ---- recombination / spectral stage / adjoint recombination, in place per slot
   double e2 = 0.0;
-  T h00 = T(0);
+  constexpr bool MEAN_NOW = !PreAll<C>::value;
+  [[maybe_unused]] T h00 = T(0);
   constexpr bool FWD = (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE);
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL || MODE == MODE_INV_NATIVE);
   [[maybe_unused]] v2f e2v = {0.0f, 0.0f};  // fp32: the lane's share of the gradient sum, in two packed halves
@@ -974,7 +1158,12 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
             y[t] = h;
             const double term = (double)h * (double)h * (p.ls[t].y + sqc);
             e2 += live ? term : 0.0;
-            if (pbase + t == 0 && live) h00 = h;  // lane 0 holds kr = 0 at position 0 (its own slot)
+            // lane 0 of column 0 holds the DC coefficient at position 0 (its own slot): ortho DC term = sum(U)/N
+            // (solver.py:223), stored right here -- carried to the end of the stage it is two registers too many where
+            // the kernel sits at its register limit (a spilled value's reload waits behind the hat_U stores)
+            // (the small grids, which request everything of the stage up front, keep it in a register to the end: MEAN_NOW)
+            if constexpr (MEAN_NOW) { if (pbase + t == 0 && live && l == 0 && kc == 0) st->meanU = (double)h / (double)C::N; }
+            else if (pbase + t == 0 && live) h00 = h;
           }
           asm volatile("" : "+v"(e2));  // do not postpone the 2E energy terms
           Ya = cx_make(y[0], y[1]); Yb = cx_make(y[2], y[3]);
@@ -997,7 +1186,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
           };
           Ya = upd(p.h01, Ya, v2f{p.la.x, p.la.y}, v2f{p.sa.x, p.sa.y});
           Yb = upd(p.h23, Yb, v2f{p.la.z, p.la.w}, v2f{p.sa.z, p.sa.w});
-          if (pbase == 0 && live) h00 = Ya.x;  // lane 0 holds kr = 0 at position 0 (its own slot)
+          if constexpr (MEAN_NOW) { if (pbase == 0 && live && l == 0 && kc == 0) st->meanU = (double)Ya.x / (double)C::N; }  // (as in fp64 above)
+          else if (pbase == 0 && live) h00 = Ya.x;
         }
       },
       [&](int pbase, const int*, Cx<T>& Ya, Cx<T>& Yb, bool live) {
@@ -1032,7 +1222,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   }
   if constexpr (MODE == MODE_STEP) STAMP(1, 5);
-  if constexpr (MODE == MODE_STEP) {
+  if constexpr (MODE == MODE_STEP && !MEAN_NOW) {
     if (l == 0 && kc == 0) st->meanU = (double)h00 / (double)C::N;  // ortho DC term = sum(U)/N (solver.py:223)
   }
   if constexpr (MODE == MODE_STEP) STAMP(1, 3);

@@ -2,6 +2,8 @@
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -306,3 +308,16 @@ def test_a_stale_or_foreign_library_is_refused(tmp_path, monkeypatch, hip_lib):
     monkeypatch.setenv('CHS_LIB_PATH', str(variant))
     path, product = _lib.resolve_library()
     assert path == str(variant) and product is False
+
+
+def test_step_kernels_do_not_spill():
+    """No scratch in any row kernel at N = 4096 and N = 8192, either element type (tools/scratch_check.py: both
+    translation units compiled to gfx950 assembly, `ScratchSize` of every k_row_* instantiation; no GPU needed).  A
+    spilled value's reload sits in the in-order vector-memory queue behind every store issued before it: in a kernel
+    that streams its results out, a 4-byte spill is a full drain."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'scratch_check.py'), '--quiet', '--row-zero'],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    # the dominant kernels of BASELINE.json's configs[2] / configs[3] / configs[4] sizes (k_col) are listed when they spill
+    for line in r.stdout.splitlines():
+        assert not re.search(r'k_col<FCfg<(double|float),(2048|4096|8192),', line), line

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""A/B timing of library variants INSIDE ONE PROCESS: every variant (chsimpy_amd/lib/variants/*.so, or paths given)
+is loaded side by side through its own ctypes binding, gets its own engine on the same GPU, and the timed calls
+alternate A, B, C, A, B, C, ... back to back -- same box, same thermal / power state, no process start between them.
+Resolves differences of a few tenths of a per cent, where one process per variant (tools/ab.sh) has +-1.5 % of noise.
+
+    python tools/ab_inproc.py [--grid 4096] [--dtype float64] [--steps 300] [--rounds 12] [--mode literal|continue|adaptive]
+                              [--glob 'a_*'] [paths...]
+Prints per variant: median / min ms per step (device time of the call, HIP events) and the median of the per-round
+ratio against the first variant."""
+import argparse
+import glob
+import importlib.util
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+KAPPA = 0.0002989112919661156
+
+
+def bind(path, tag):
+    """A private copy of chsimpy_amd._lib bound to `path`."""
+    spec = importlib.util.spec_from_file_location(f'chsimpy_amd._lib_{tag}', os.path.join(ROOT, 'chsimpy_amd', '_lib.py'),
+                                                  submodule_search_locations=None)
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = 'chsimpy_amd'
+    spec.loader.exec_module(mod)
+    os.environ['CHS_LIB_PATH'] = path
+    try:
+        mod.load()
+    finally:
+        del os.environ['CHS_LIB_PATH']
+    return mod
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--grid', type=int, default=4096)
+    ap.add_argument('--dtype', default='float64')
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--rounds', type=int, default=12)
+    ap.add_argument('--warm', type=int, default=300)
+    ap.add_argument('--mode', default='continue', choices=['literal', 'continue', 'adaptive', 'estop'])
+    ap.add_argument('--delt-max', type=float, default=None)
+    ap.add_argument('--glob', default='*')
+    ap.add_argument('paths', nargs='*')
+    a = ap.parse_args()
+    paths = a.paths or sorted(glob.glob(os.path.join(ROOT, 'chsimpy_amd', 'lib', 'variants', a.glob + '.so')))
+    assert paths, 'no variants'
+    import chsimpy_amd
+    engines = []
+    for i, path in enumerate(paths):
+        mod = bind(os.path.abspath(path), str(i))
+        p = chsimpy_amd.Parameters()
+        p.N, p.ntmax, p.full_sim, p.kappa_tilde, p.dtype, p.engine = a.grid, 10 ** 9, a.mode != 'estop', KAPPA, a.dtype, 'fast'
+        if a.mode == 'adaptive':
+            p.adaptive_time = True
+            p.delt_max = a.delt_max or (6e-11 if a.grid == 8192 else 1.2e-10 * (4096 / a.grid))
+        s = chsimpy_amd.Solver(p)
+        c0 = s._consts()
+        consts = mod.chs_consts()             # (the structure type of THIS binding)
+        for name, _t in c0._fields_:
+            setattr(consts, name, getattr(c0, name))
+        eng = mod.Engine(consts, s.solution.lam)
+        st = s._pcg_state0['state']
+        eng.init_U_pcg64(p.XXX, p.XXX * 0.01, st['state'], st['inc'])
+        eng.prepare()
+        rows, rc = eng.step_n(max(a.warm, 520 if a.mode == 'adaptive' else 0))
+        assert rc == 0, (path, rc)
+        engines.append((os.path.basename(path)[:-3], eng))
+    kw = dict(rederive_hat=True, last_call=False) if a.mode == 'literal' else {}
+    ms = {n: [] for n, _ in engines}
+    wall = {n: [] for n, _ in engines}
+    for r in range(a.rounds):
+        order = engines if r % 2 == 0 else engines[::-1]     # (alternate the order: nobody always runs behind the same one)
+        for n, eng in order:
+            t0 = time.perf_counter()
+            rows, rc = eng.step_n(a.steps, **kw)
+            wall[n].append((time.perf_counter() - t0) * 1e3 / a.steps)
+            assert rc == 0 and rows.shape[0] == a.steps, (n, rc, rows.shape)
+            ms[n].append(eng.last_step_ms() / a.steps)
+    ref = engines[0][0]
+    print(f"# N={a.grid} {a.dtype} mode={a.mode} steps/call={a.steps} rounds={a.rounds} (device ms per step; ratio = variant / {ref}, per round)")
+    for n, _ in engines:
+        ratios = [x / y for x, y in zip(ms[n], ms[ref])]
+        print(f"{n:28s} median {statistics.median(ms[n]):.5f}  min {min(ms[n]):.5f}  wall median {statistics.median(wall[n]):.5f}  "
+              f"ratio median {statistics.median(ratios):.4f}  [{min(ratios):.4f} .. {max(ratios):.4f}]  "
+              f"-> {1e3 / statistics.median(ms[n]):.0f} steps/s")
+    for _, eng in engines:
+        eng.close()
+
+
+if __name__ == '__main__':
+    main()
