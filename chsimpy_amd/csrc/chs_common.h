@@ -103,7 +103,11 @@ __device__ __forceinline__ double block_min(double v, double* scratch) {
 // register limit spills such a long-lived index, and a 4-byte spill reload sits in the in-order vmcnt queue behind every
 // store issued before it.  The wavefront's number goes to an SGPR once; the lane number is two v_mbcnt wherever it is
 // needed (volatile: never carried from one use to the next either).  One-dimensional blocks of whole wavefronts only.
-__device__ __forceinline__ int chs_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int chs_wave_id() {
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __builtin_assume(w >= 0 && w < 16);   // (what is derived from it stays unsigned 32-bit offset arithmetic)
+  return w;
+}
 __device__ __forceinline__ int chs_lane_id() {
   int x;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));

@@ -23,6 +23,10 @@ using F1024 = FCfg<double, 1024, 64, 256, 4, 8, 4, 4, 2, 1, 4, 2>;
 // CUs; the powers alone: no change.  profiles/r03_ab_xpair.txt)
 using F2048 = FCfg<double, 2048, 64, 256, 8, 16, 1, 8, 2, 0, 8, 2>;
 using F2048C = F2048;
+#ifndef CHS_F2048C_LAM_SGPR
+#define CHS_F2048C_LAM_SGPR 0   // (with it: 16 bytes of scratch)
+#endif
+template <> struct ColLamSgpr<F2048C> { static constexpr bool value = (CHS_F2048C_LAM_SGPR != 0); };
 // (the pass twiddles of the row kernel in LDS, which pay from N = 4096 upwards, cost 1 % here: 17.1 k against 17.25 k steps/s)
 // N = 4096: two wavefronts per transform, 16 complex values per lane, four radix passes
 #ifndef CHS_ROW_WPS
@@ -73,6 +77,10 @@ using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, CHS_PAD1, CH
 #define CHS_F4096C_TW_LDS 2
 #endif
 template <> struct ColTwLds<F4096C> { static constexpr int value = CHS_F4096C_TW_LDS; };
+#ifndef CHS_F4096C_LAM_SGPR
+#define CHS_F4096C_LAM_SGPR 1
+#endif
+template <> struct ColLamSgpr<F4096C> { static constexpr bool value = (CHS_F4096C_LAM_SGPR != 0); };
 // Stage-in by LDS-DMA (round 4; chs_fast_kernels.h: DmaStage) in this one-workgroup-per-item kernel -- every piece of
 // both halves of the tile requested at kernel entry, one wait, no staging registers, 32 ds_write_b64 per thread fewer,
 // parity green -- measured 2.8 % SLOWER per step (k_col +5 %), in-process A/B on one box: 0.2201 against 0.2139 ms
@@ -98,6 +106,7 @@ using F8192C = FCfg<double, 8192, 256, 512, 8, 8, 8, 8, 2, 1, 16, 2, CHS_F8192_C
 #define CHS_F8192C_TW_LDS 2
 #endif
 template <> struct ColTwLds<F8192C> { static constexpr int value = CHS_F8192C_TW_LDS; };
+template <> struct ColLamSgpr<F8192C> { static constexpr bool value = false; };   // (with it: 44 bytes of scratch)
 #ifndef CHS_F8192_ROW_TW_LDS
 #define CHS_F8192_ROW_TW_LDS 3
 #endif

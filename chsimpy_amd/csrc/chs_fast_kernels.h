@@ -195,8 +195,11 @@ __device__ __forceinline__ int launder(int x);
 // FRESH (fp64, whose row kernels sit at their 128 registers and spilled these indices): lane index and row within the
 // workgroup are recomputed per phase.  Otherwise (fp32: room to spare, the recomputation only adds instructions -- N=8192
 // fp32 measured 1.1 % slower with it) the values taken at the top of the kernel are passed through an opaque copy.
+#ifndef CHS_FRESH_MIN_E
+#define CHS_FRESH_MIN_E 16   // (8 values per lane, N <= 1024: registers to spare; N=1024 measured 2.9 % slower with it)
+#endif
 template <class C>
-struct FreshLane { static constexpr bool value = (sizeof(typename C::T) == 8); };
+struct FreshLane { static constexpr bool value = (sizeof(typename C::T) == 8) && (C::E >= CHS_FRESH_MIN_E); };
 template <class C, bool FORCE = false>
 __device__ __forceinline__ int row_l(int wave, int l_top) {
   if constexpr (FORCE || FreshLane<C>::value) { int l, sub; row_lane_map<C>(wave, l, sub); return l; }
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
       T a = cx_re(z[e]), b = cx_im(z[e]);
       mu(a); mu(b);
       z[e] = cx_make(a, b);
+      __builtin_amdgcn_sched_barrier(0);   // (as in the fused row kernel: one value pair at a time)
     }
     if (dom > (unsigned)(CHS_LOGTAB_N - 1)) s2 = __builtin_nan("");  // U left (0,1): L2 of this step becomes NaN
     // (the wavefront sums go to LDS here: no register carries the sum across the transform)
@@ -842,6 +846,11 @@ struct ColStage {
 // their powers (tw0_load<POW>) -- where the whole table would cost the second workgroup of a CU (chs_fast_f32.hip)
 template <class C>
 struct ColTwLds { static constexpr int value = 1; };
+// k_col<MODE_STEP> sits at its 256 registers; whether the step's two coefficients are forced back into scalar registers
+// in front of the spectral stage (4 VGPRs less) is chosen per configuration by what the register allocator makes of it
+// (tools/scratch_check.py: no spill in any k_col from N = 1024 upwards)
+template <class C>
+struct ColLamSgpr { static constexpr bool value = true; };
 template <class C>
 constexpr int col_tw_lds_elems() {
   if (ColTwLds<C>::value == 1) return 2 * ((C::R0 - 1) * C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
@@ -1145,6 +1154,17 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL || MODE == MODE_INV_NATIVE);
   [[maybe_unused]] v2f e2v = {0.0f, 0.0f};  // fp32: the lane's share of the gradient sum, in two packed halves
   if constexpr (MODE == MODE_STEP) {
+    if constexpr (ColLamSgpr<C>::value) {
+      // the step's coefficients are uniform but reach this point through a select (entry load | the gate's LDS box) and
+      // would sit in four VGPRs all through the stage that needs every one of them: back into scalar registers
+      auto uni = [](double x) {
+        const long long b = __double_as_longlong(x);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      };
+      lam1 = uni(lam1); lam2 = uni(lam2);
+    }
     // fp32: the coefficients of this launch as floats (after the gate: lam1/lam2 are this step's)
     [[maybe_unused]] const float lam1f = (float)lam1, lam2f = (float)lam2, lcf = (float)lc, sqcf = (float)sqc;
     recombine<C, true, true, true>(z, tb, l, fetch,

@@ -48,6 +48,7 @@ def main():
     ap.add_argument('--mode', default='continue', choices=['literal', 'continue', 'adaptive', 'estop'])
     ap.add_argument('--delt-max', type=float, default=None)
     ap.add_argument('--glob', default='*')
+    ap.add_argument('--profile', type=int, default=0, help='afterwards: per-kernel device time (HIP events) over this many steps, per variant')
     ap.add_argument('paths', nargs='*')
     a = ap.parse_args()
     paths = a.paths or sorted(glob.glob(os.path.join(ROOT, 'chsimpy_amd', 'lib', 'variants', a.glob + '.so')))
@@ -91,6 +92,13 @@ def main():
         print(f"{n:28s} median {statistics.median(ms[n]):.5f}  min {min(ms[n]):.5f}  wall median {statistics.median(wall[n]):.5f}  "
               f"ratio median {statistics.median(ratios):.4f}  [{min(ratios):.4f} .. {max(ratios):.4f}]  "
               f"-> {1e3 / statistics.median(ms[n]):.0f} steps/s")
+    if a.profile:
+        for rep in range(2):
+            for n, eng in engines:
+                msk, calls = eng.profile_steps(a.profile)
+                names = eng.kernel_names()
+                if rep == 1:
+                    print(f"{n:28s} " + '  '.join(f"{names[i]} {msk[i] / calls[i] * 1e3:.1f}us" for i in range(len(names)) if names[i] and calls[i] > 0))
     for _, eng in engines:
         eng.close()
 
