@@ -34,7 +34,13 @@
 #define CHS_G8192_XPAIR 0
 #endif
 using G8192 = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192_WPS, CHS_F32_CT, CHS_G8192_XPAIR>;
-using G8192C = FCfg<float, 8192, 128, 256, 16, 16, 1, 16, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT>;
+#ifndef CHS_G8192C_THREADS
+#define CHS_G8192C_THREADS 256
+#endif
+#ifndef CHS_G8192C_XPAIR
+#define CHS_G8192C_XPAIR -1
+#endif
+using G8192C = FCfg<float, 8192, 128, CHS_G8192C_THREADS, 16, 16, 1, 16, 2, 1, 16, CHS_G8192C_WPS, CHS_F32_CT, CHS_G8192C_XPAIR>;
 template <> struct ColTwLds<G8192C> { static constexpr int value = CHS_G8192C_TW_LDS; };
 #ifndef CHS_G8192_ROW_TW_LDS
 #define CHS_G8192_ROW_TW_LDS 2

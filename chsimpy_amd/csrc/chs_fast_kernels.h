@@ -825,7 +825,8 @@ struct ColStage {
   static constexpr int ROWS = C::N / 2;        // rows per round
   static constexpr int ELEMS = LINES * LP;     // staging elements
   static constexpr int JR = C::R0 / 4;         // pass-0 half-indices j per round
-  static constexpr int PW = (C::C % 2 == 0) ? 2 : 1;            // elements per piece (a 16-byte piece when it can be)
+  // elements per piece: a 16-byte piece when it can be (fp64: 2 columns; fp32: 4 columns), else 8 bytes, else one element
+  static constexpr int PW = (sizeof(typename C::T) == 4 && C::C % 4 == 0) ? 4 : ((C::C % 2 == 0) ? 2 : 1);
   static constexpr int PER = ROWS * C::C / (PW * C::THREADS);   // pieces per thread per round
   static constexpr int Q = C::CT / C::C;       // workgroups per tile
   static_assert(C::R0 >= 4, "pass-0 radix must be >= 4");
@@ -1085,6 +1086,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         constexpr bool NT = (MODE == MODE_FWD_NATIVE);  // the entry's intermediate (k_row_fwd2's Ta): its only read
         if constexpr (PW == 1) {
           stage[rho][i] = NT ? __builtin_nontemporal_load(src) : *src;
+        } else if constexpr (PW == 4) {
+          chs_f4v v;
+          if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const chs_f4v*>(src));
+          else v = *reinterpret_cast<const chs_f4v*>(src);
+          stage[rho][4 * i] = v.x; stage[rho][4 * i + 1] = v.y; stage[rho][4 * i + 2] = v.z; stage[rho][4 * i + 3] = v.w;
         } else if constexpr (sizeof(T) == 8) {
           if constexpr (NT) {
             const chs_d2v v = __builtin_nontemporal_load(reinterpret_cast<const chs_d2v*>(src));
@@ -1110,8 +1116,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       for (int i = 0; i < PER; ++i) {
         const int f = PW * (threadIdx.x + i * C::THREADS);
         const int lo = CS::loff(f);
-        lds[lo] = stage[rho][PW * i];
-        if constexpr (PW == 2) lds[lo + 1] = stage[rho][2 * i + 1];
+#pragma unroll
+        for (int e = 0; e < PW; ++e) lds[lo + e] = stage[rho][PW * i + e];
       }
       if (rho == 0) request(1);
       __syncthreads();
@@ -1167,7 +1173,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     }
     // fp32: the coefficients of this launch as floats (after the gate: lam1/lam2 are this step's)
     [[maybe_unused]] const float lam1f = (float)lam1, lam2f = (float)lam2, lcf = (float)lc, sqcf = (float)sqc;
-    recombine<C, true, true, true>(z, tb, l, fetch,
+#ifndef CHS_COL_PIPE
+#define CHS_COL_PIPE 1   // 0: the spectral stage fetches slot k in slot k (fewer live registers; measured)
+#endif
+    recombine<C, true, true, (CHS_COL_PIPE != 0)>(z, tb, l, fetch,
       [&](int pbase, const int*, Cx<T>& Ya, Cx<T>& Yb, bool live, const Fetched& p) {
         if constexpr (sizeof(T) == 8) {
           T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
@@ -1279,6 +1288,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
         T* dst = tile + CS::goff(rho, f, hh);
         if constexpr (CS::PW == 1) {
           *dst = lds[lo];
+        } else if constexpr (CS::PW == 4) {
+          chs_f4v v; v.x = lds[lo]; v.y = lds[lo + 1]; v.z = lds[lo + 2]; v.w = lds[lo + 3];
+          *reinterpret_cast<chs_f4v*>(dst) = v;
         } else {
           const T a = lds[lo], b = lds[lo + 1];
           if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(a, b);
