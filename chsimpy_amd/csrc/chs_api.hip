@@ -524,12 +524,22 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   // EnergieEut(U) and its sum of squares on the device, and a call that finds them continues the loop where it
   // stopped -- hat_U is the array the reference would recompute as dctn(idctn(hat_U)) (solver.py:159), equal up
   // to rounding; CHS_STEP_REDERIVE_HAT asks for the literal recomputation.
-  // (a caller that asks for the literal re-derivation does so at every call: nothing to keep for it either)
-  E->keepResident = fused && !E->dc.adaptive_time && !profile && !(flags & (CHS_STEP_LAST_CALL | CHS_STEP_REDERIVE_HAT));
-  const bool cont = fused && E->resident && E->hat_valid && !(flags & CHS_STEP_REDERIVE_HAT) && !profile;
+  // A caller that asks for the literal re-derivation (CHS_STEP_REDERIVE_HAT) gets hat_U = dctn(U) recomputed at every
+  // call; what such a call still takes over from its predecessor is the OTHER thing the last fused step leaves: T1 = the
+  // row transform of EnergieEut(U) and its sum of squares -- a function of the unchanged field U alone, which k_row_fwd2
+  // would only compute again bit for bit.  (CHS_REDERIVE_KEEPS_T1=0 in the environment: recompute that too.)
+  static const bool keep_t1 = [] { const char* e = getenv("CHS_REDERIVE_KEEPS_T1"); return !(e && e[0] == '0'); }();
+  const bool rederive = (flags & CHS_STEP_REDERIVE_HAT) != 0;
+  E->keepResident = fused && !E->dc.adaptive_time && !profile && !(flags & CHS_STEP_LAST_CALL) && (!rederive || keep_t1);
+  const bool cont = fused && E->resident && E->hat_valid && !rederive && !profile;
+  const bool cont_t1 = fused && E->resident && rederive && keep_t1 && !profile;
   if (nsteps > 0) E->resident = false;
   if (cont && nsteps > 0) {
     // nothing to do: T1, partMu and hat_U are in place
+  } else if (cont_t1 && nsteps > 0) {
+    // hat_U = dctn(U), literally; T1 and partMu are in place
+    if ((rc = chs_fast_enter_hat(E))) return rc;
+    E->hat_valid = true;
   } else if (derive && fused && nsteps > 0) {
     // hat_U = dctn(U) and the first step's row transform of EnergieEut(U) from one sweep of U
     if ((rc = chs_fast_enter_fused(E))) return rc;

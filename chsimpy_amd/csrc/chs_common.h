@@ -353,6 +353,7 @@ void chs_fast_free(Engine* E);
 int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse);  // natural in/out (tests)
 int chs_fast_enter(Engine* E);   // hat_U <- dctn(U) in engine-native order (solver.py:159)
 int chs_fast_enter_fused(Engine* E);       // both of them with one sweep of U
+int chs_fast_enter_hat(Engine* E);         // hat_U <- dctn(U) alone: the first step's operand T1 is still on the device
 int chs_fast_prologue(Engine* E);          // T1 <- row DCT of EnergieEut(U) for the first step of a call
 int chs_fast_step(Engine* E, bool first, bool last); // [k_pre,] k_col, fused row kernel, k_step_tail
 int chs_fast_step_unfused(Engine* E);      // jitter path: every kernel separate, U complete in HBM

@@ -156,7 +156,7 @@ int chs_fast_dct2d(Engine* E, const void* in, void* out, bool inverse) {
   FastPlan* P = (FastPlan*)E->dTw;
   int rc;
   if (!inverse) {
-    if ((rc = P->row_fwd(E, in, E->dT1, false))) return rc;
+    if ((rc = P->row_fwd(E, in, E->dT1, ROW_FWD_PLAIN))) return rc;
     return P->col(E, MODE_FWD_NATURAL, E->dT1, nullptr, E->dHat, out);
   }
   if ((rc = P->col(E, MODE_INV_NATURAL, nullptr, E->dT1, E->dHat, (void*)in))) return rc;
@@ -176,7 +176,7 @@ int chs_fast_recover_u(Engine* E) {
 int chs_fast_enter(Engine* E) {
   FastPlan* P = (FastPlan*)E->dTw;
   int rc;
-  if ((rc = P->row_fwd(E, E->dU, E->dT1, false))) return rc;
+  if ((rc = P->row_fwd(E, E->dU, E->dT1, ROW_FWD_PLAIN))) return rc;
   return P->col(E, MODE_FWD_NATIVE, E->dT1, nullptr, E->dHat, nullptr);
 }
 
@@ -190,6 +190,9 @@ static void select_partial_set(Engine* E) {
   E->dPartE2 = E->partSet[par][2]; E->dPartRa = E->partSet[par][3];
 }
 
+#ifndef CHS_ENTRY_REVERSE
+#define CHS_ENTRY_REVERSE 0
+#endif
 // Entry of a call on the fused pipeline: hat_U <- dctn(U) (solver.py:159) and the prologue below with
 // one sweep of U instead of two (k_row_fwd2), the row transform of U parked in the idle T2 buffer.
 int chs_fast_enter_fused(Engine* E) {
@@ -204,9 +207,20 @@ int chs_fast_enter_fused(Engine* E) {
   // k_col<FWD_NATIVE> writes hat_U tile by tile in ascending order.  The first step's k_col walks the tiles in ASCENDING
   // order too (0; 1 = descending: what was written last is read first -- measured 2.3 % slower on a literal 20-step call,
   // profiles/r04_ab_dma.txt), whatever the parity of the steps of earlier calls; then the directions alternate (CHS_COL_ZIGZAG)
-#ifndef CHS_ENTRY_REVERSE
-#define CHS_ENTRY_REVERSE 0
-#endif
+  if (CHS_ENTRY_REVERSE >= 0) E->stepCount = CHS_ENTRY_REVERSE;
+  return P->col(E, MODE_FWD_NATIVE, E->dT2, nullptr, E->dHat, nullptr);
+}
+
+// Entry of a literal call that finds the first step's operand on the device: the previous call's last step was the fused
+// row kernel (it stored U in full AND left T1 = the row transform of EnergieEut(U) with its sum of squares, exactly what
+// the steps inside a call hand to each other), nothing has touched the field since.  hat_U = dctn(U) is recomputed here,
+// literally (solver.py:159): row pass of U (streamed) into the idle T2 buffer, column pass into hat_U.  What is NOT
+// recomputed is EnergieEut(U) and its row transform -- a function of the unchanged U, bit for bit what k_row_fwd2 would
+// produce again.
+int chs_fast_enter_hat(Engine* E) {
+  FastPlan* P = (FastPlan*)E->dTw;
+  int rc;
+  if ((rc = P->row_fwd(E, E->dU, E->dT2, ROW_FWD_STREAM))) return rc;
   if (CHS_ENTRY_REVERSE >= 0) E->stepCount = CHS_ENTRY_REVERSE;
   return P->col(E, MODE_FWD_NATIVE, E->dT2, nullptr, E->dHat, nullptr);
 }
@@ -216,7 +230,7 @@ int chs_fast_prologue(Engine* E) {
   E->tailDeferred = false;
   select_partial_set(E);  // sum(mu^2) must land where the first step's k_pre looks for it
   chs_slot_begin(E, SLOT_MU);
-  const int rc = P->row_fwd(E, E->dU, E->dT1, true);
+  const int rc = P->row_fwd(E, E->dU, E->dT1, ROW_FWD_POINTWISE);
   chs_slot_end(E, SLOT_MU);
   return rc;
 }

@@ -333,7 +333,10 @@ __device__ __forceinline__ int launder(int x) {
 // block's sum(mu^2) is recorded (solver.py:225); otherwise a plain transform.
 // (Prologue of a solve_or_resume call, and the unfused/jitter path.)
 // ---------------------------------------------------------------------------
-template <class C, bool POINTWISE>
+// STREAM (the row half of hat_U = dctn(U) at the entry of a call that finds the first step's operand already on the
+// device, chs_fast_enter_hat): U is read for the last time and the result is read once, by k_col<FWD_NATIVE> right behind
+// this kernel -- non-temporal loads and stores, as in k_row_fwd2.
+template <class C, bool POINTWISE, bool STREAM = false>
 __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C::T* __restrict__ U, typename C::T* __restrict__ T1,
                                                     FTables<typename C::T> tb, DevConsts dc,
                                                     const DevState* __restrict__ st, double* __restrict__ partMu) {
@@ -359,8 +362,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
 #pragma unroll
     for (int j = 0; j < C::R0 / 2; ++j) {
       T q1[4], q2[4];
-      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+      if constexpr (STREAM) {
+        load4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+        load4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+      } else {
+        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
+      }
       pack_quads<C>(q1, q2, q, j, z);
     }
   }
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
                             [&](int pbase, const int* idx, Cx<T>& Ya, Cx<T>& Yb, bool live, NoFetch) {
     if (live) {
       const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
-      row_store<C>(T1, rw, pbase, launder(lr), idx, y);
+      row_store<C, STREAM>(T1, rw, pbase, launder(lr), idx, y);
     }
   }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (POINTWISE) {
@@ -1312,12 +1320,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
 // host side
 // ---------------------------------------------------------------------------
 enum { ROW_INV_PLAIN = 0, ROW_INV_DIAG = 1, ROW_INV_FUSED = 2, ROW_INV_FUSED_ADAPT = 3 };
+enum { ROW_FWD_PLAIN = 0, ROW_FWD_POINTWISE = 1, ROW_FWD_STREAM = 2 };
 
 struct FastPlan {
   int N, G, R0, RA, RB, RL, threads, col_tiles;
   void* tables = nullptr;  // one device allocation
   size_t off_tw0, off_twa, off_twb, off_wp, off_t1, off_t2, off_lam4 = 0, off_sin4 = 0;  // element offsets
-  int (*row_fwd)(Engine*, const void*, void*, bool) = nullptr;
+  int (*row_fwd)(Engine*, const void*, void*, int) = nullptr;   // mode: ROW_FWD_PLAIN / _POINTWISE / _STREAM
   int (*row_fwd2)(Engine*, const void*, void*, void*) = nullptr;
   int (*row_inv)(Engine*, int, const void*, void*, void*) = nullptr;
   int (*col)(Engine*, int, const void*, void*, void*, void*) = nullptr;
@@ -1355,6 +1364,7 @@ struct Launch {
     int rc;
     if ((rc = set_lds(k_row_fwd<C, true>, row_lds))) return rc;
     if ((rc = set_lds(k_row_fwd<C, false>, row_lds))) return rc;
+    if ((rc = set_lds(k_row_fwd<C, false, true>, row_lds))) return rc;
     if ((rc = set_lds(k_row_fwd2<C>, row_lds))) return rc;
     if ((rc = set_lds(k_row_inv<C, false, false>, row_lds))) return rc;
     if ((rc = set_lds(k_row_inv<C, true, false>, row_lds))) return rc;
@@ -1371,11 +1381,14 @@ struct Launch {
     if ((rc = set_lds(k_col<CC, MODE_INV_NATIVE>, col_lds))) return rc;
     return CHS_OK;
   }
-  static int row_fwd(Engine* E, const void* in, void* out, bool pointwise) {
+  static int row_fwd(Engine* E, const void* in, void* out, int mode) {
     const int grid = C::N / C::C;
-    if (pointwise)
+    if (mode == ROW_FWD_POINTWISE)
       k_row_fwd<C, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
                                                             E->dPartMu);
+    else if (mode == ROW_FWD_STREAM)
+      k_row_fwd<C, false, true><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
+                                                                   E->dPartMu);
     else
       k_row_fwd<C, false><<<grid, C::THREADS, row_lds, E->stream>>>((const T*)in, (T*)out, get_tables<T>(E), E->dc, E->dState,
                                                              E->dPartMu);

@@ -162,13 +162,16 @@ int chs_step_n(chs_handle h, int64_t nsteps, int32_t flags, double* rows, int64_
                                 previous call (used to feed per-step host jitter noise while
                                 keeping the reference's carried hat_U, solver.py:206-211) */
 
-#define CHS_STEP_REDERIVE_HAT 2 /* (implies that the call's last step prepares no continuation either, like CHS_STEP_LAST_CALL)
-                                  recompute hat_U = dctn(U) on entry (the literal solver.py:159) even when the
+#define CHS_STEP_REDERIVE_HAT 2 /* recompute hat_U = dctn(U) on entry (the literal solver.py:159) even when the
                                   previous call left the loop's state on the device.  Without it a call with a
                                   fixed time step that follows a completed call (no new field, state or noise
                                   in between) continues that call's loop: hat_U is carried instead of being
                                   recomputed from the field it was inverted to -- the same array up to
-                                  rounding -- and the sequence of calls gives bit for bit what one call gives */
+                                  rounding -- and the sequence of calls gives bit for bit what one call gives.
+                                  What a re-deriving call still takes over from a completed predecessor (same
+                                  conditions) is the row transform of EnergieEut(U) for its first step, which the
+                                  predecessor's last step left as every step inside a call does: a function of the
+                                  unchanged field alone.  Environment CHS_REDERIVE_KEEPS_T1=0: recompute it too. */
 #define CHS_STEP_LAST_CALL 4   /* the run ends with this call: its last step does not prepare a continuation (the
                                   forward row pass of a step that will not come); a later call is still correct,
                                   it enters through hat_U = dctn(U) */

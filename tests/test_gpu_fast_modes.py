@@ -207,14 +207,19 @@ def test_calls_continue_the_device_loop(gpu, N, full_sim):
     U1, td1 = sol1.U.copy(), sol1.timedata.data().copy()
     one.close()
     runs = {}
-    for rederive in (False, True):
+    # rederive 'full': the literal call with NOTHING taken over -- the residency is ended between the calls (chs_set_state),
+    # so every call enters through k_row_fwd2 (hat_U = dctn(U) and the row transform of EnergieEut(U) from one sweep of U);
+    # rederive True: hat_U = dctn(U) recomputed, the first step's operand taken over from the previous call's last step
+    for rederive in (False, True, 'full'):
         s = chsimpy_amd.Solver(make(N, nt, 'fast', full_sim=full_sim))
-        s.rederive_hat = rederive
+        s.rederive_hat = bool(rederive)
         s.prepare()
         o = orc.OracleSolver(orc.make_params(N, nt, full_sim=full_sim)) if N <= 128 else None
         if o:
             o.prepare()
         for c in chunks:
+            if rederive == 'full':
+                s._engine.set_state(s._engine.get_state())
             sol = s.solve_or_resume(c)
             if o:
                 o.solve_or_resume(c)
@@ -232,6 +237,9 @@ def test_calls_continue_the_device_loop(gpu, N, full_sim):
     # the literal recomputation differs from the carried array by rounding only
     assert np.allclose(runs[True][0], U1, rtol=1e-11, atol=0), relerr(runs[True][0], U1)
     assert not np.array_equal(runs[True][0], U1)
+    # ... and taking the first step's operand over (a function of the unchanged field) changes nothing at all
+    assert np.array_equal(runs[True][0], runs['full'][0]) and np.array_equal(runs[True][1], runs['full'][1]), \
+        relerr(runs[True][0], runs['full'][0])
     log_line(f"N={N} full_sim={full_sim} chunks {chunks}: carried hat_U == one call bit for bit; "
              f"rederive_hat vs carried max rel err U={relerr(runs[True][0], U1):.3e}")
 
