@@ -18,6 +18,7 @@ CHS_STOP_NONE, CHS_STOP_ENERGY, CHS_STOP_TIME_LIMIT = 0, 1, 2
 CHS_STEP_CARRY_HAT = 1
 CHS_STEP_REDERIVE_HAT = 2
 CHS_STEP_LAST_CALL = 4
+CHS_STEP_KEEP_T1 = 8
 CHS_NKERNELS = 8
 
 STOP_NAMES = {CHS_STOP_NONE: 'None', CHS_STOP_ENERGY: 'energy', CHS_STOP_TIME_LIMIT: 'time-limit'}
@@ -218,13 +219,14 @@ class Engine:
         self._check(self.lib.chs_prepare(self._h, _dptr(row)), 'chs_prepare')
         return row
 
-    def step_n(self, nsteps, carry_hat=False, rederive_hat=False, last_call=False):
+    def step_n(self, nsteps, carry_hat=False, rederive_hat=False, last_call=False, keep_t1=False):
         """Returns (rows[k,9], rc) -- rc is CHS_OK or CHS_ENAN (rows then end with the NaN row)."""
         nsteps = int(max(nsteps, 0))
         rows = np.empty((max(nsteps, 1), 9), dtype=np.float64)
         done = C.c_int64(0)
         rc = self.lib.chs_step_n(self._h, nsteps, (CHS_STEP_CARRY_HAT if carry_hat else 0) | (CHS_STEP_REDERIVE_HAT if rederive_hat else 0)
-                                 | (CHS_STEP_LAST_CALL if last_call else 0), _dptr(rows), C.byref(done))
+                                 | (CHS_STEP_LAST_CALL if last_call else 0) | (CHS_STEP_KEEP_T1 if keep_t1 else 0),
+                                 _dptr(rows), C.byref(done))
         if rc not in (CHS_OK, CHS_ENAN):
             self._check(rc, 'chs_step_n')
         return rows[:done.value].copy(), rc

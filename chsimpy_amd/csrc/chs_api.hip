@@ -527,8 +527,10 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   // A caller that asks for the literal re-derivation (CHS_STEP_REDERIVE_HAT) gets hat_U = dctn(U) recomputed at every
   // call; what such a call still takes over from its predecessor is the OTHER thing the last fused step leaves: T1 = the
   // row transform of EnergieEut(U) and its sum of squares -- a function of the unchanged field U alone, which k_row_fwd2
-  // would only compute again bit for bit.  (CHS_REDERIVE_KEEPS_T1=0 in the environment: recompute that too.)
-  static const bool keep_t1 = [] { const char* e = getenv("CHS_REDERIVE_KEEPS_T1"); return !(e && e[0] == '0'); }();
+  // would only compute again bit for bit -- when the caller allows it (CHS_STEP_KEEP_T1; off by default: measured, it
+  // buys nothing at N=4096 -- the entry shrinks from 215 to 152 us, the call's last step, now the fused kernel, grows by
+  // as much: profiles/r04_ab_entry.txt).
+  const bool keep_t1 = (flags & CHS_STEP_KEEP_T1) != 0;
   const bool rederive = (flags & CHS_STEP_REDERIVE_HAT) != 0;
   E->keepResident = fused && !E->dc.adaptive_time && !profile && !(flags & CHS_STEP_LAST_CALL) && (!rederive || keep_t1);
   const bool cont = fused && E->resident && E->hat_valid && !rederive && !profile;

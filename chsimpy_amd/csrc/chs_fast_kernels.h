@@ -335,7 +335,7 @@ __device__ __forceinline__ int launder(int x) {
 // ---------------------------------------------------------------------------
 // STREAM (the row half of hat_U = dctn(U) at the entry of a call that finds the first step's operand already on the
 // device, chs_fast_enter_hat): U is read for the last time and the result is read once, by k_col<FWD_NATIVE> right behind
-// this kernel -- non-temporal loads and stores, as in k_row_fwd2.
+// this kernel -- non-temporal stores, as k_row_fwd2's.
 template <class C, bool POINTWISE, bool STREAM = false>
 __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C::T* __restrict__ U, typename C::T* __restrict__ T1,
                                                     FTables<typename C::T> tb, DevConsts dc,
@@ -362,13 +362,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd(const typename C
 #pragma unroll
     for (int j = 0; j < C::R0 / 2; ++j) {
       T q1[4], q2[4];
-      if constexpr (STREAM) {
-        load4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-        load4_nt<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
-      } else {
-        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
-        load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
-      }
+      // (ordinary loads also with STREAM: non-temporal loads that miss every cache took this kernel from ~75 to 188 us at
+      // N=4096 fp64 -- k_row_fwd2's non-temporal second read of U hits L2)
+      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m1 + C::L1 * j)) * (unsigned)sizeof(T)), q1);
+      load4<T>(at_boff(U, (urow + 4u * (unsigned)(m2 + C::L1 * j)) * (unsigned)sizeof(T)), q2);
       pack_quads<C>(q1, q2, q, j, z);
     }
   }
@@ -605,7 +602,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
       }
     }
   };
-  if (FUSE && store_u) put_u(std::true_type{});
+#ifndef CHS_FUSED_U_NT
+#define CHS_FUSED_U_NT 1
+#endif
+  if (FUSE && store_u && CHS_FUSED_U_NT) put_u(std::true_type{});
   else if (write_u) put_u(std::false_type{});
   if constexpr (DIAG) {
     // np.gradient edge columns: (U[r,1]-U[r,0]) and (U[r,N-1]-U[r,N-2]) live in lane 0

@@ -39,6 +39,9 @@ class Solver:
         # loop where it stopped, hat_U included; True recomputes hat_U = dctn(U) at every call as solver.py:159
         # does (the same array up to rounding, one transform more per call)
         self.rederive_hat = False
+        # with rederive_hat: take the first step's operand (row transform of EnergieEut(U)) over from the previous call's
+        # last step instead of computing it again (CHS_STEP_KEEP_T1; the same run bit for bit, no faster at N=4096)
+        self.rederive_keeps_t1 = False
         self._U_init = None
         # initial concentration field, solver.py:59-82
         if U_init is not None:
@@ -192,7 +195,7 @@ class Solver:
         if not jitter_on:
             eng.set_jitter_noise(0.0, None)
             # (a call that reaches ntmax ends the run: its last step need not prepare a continuation)
-            rows, rc = eng.step_n(count, rederive_hat=self.rederive_hat,
+            rows, rc = eng.step_n(count, rederive_hat=self.rederive_hat, keep_t1=self.rederive_hat and self.rederive_keeps_t1,
                                   last_call=self.solution.computed_steps + count >= p.ntmax)
             self._absorb(rows, rc, count)
         elif self._pcg is not None and self.device_rng:

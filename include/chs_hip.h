@@ -168,10 +168,13 @@ int chs_step_n(chs_handle h, int64_t nsteps, int32_t flags, double* rows, int64_
                                   in between) continues that call's loop: hat_U is carried instead of being
                                   recomputed from the field it was inverted to -- the same array up to
                                   rounding -- and the sequence of calls gives bit for bit what one call gives.
-                                  What a re-deriving call still takes over from a completed predecessor (same
-                                  conditions) is the row transform of EnergieEut(U) for its first step, which the
-                                  predecessor's last step left as every step inside a call does: a function of the
-                                  unchanged field alone.  Environment CHS_REDERIVE_KEEPS_T1=0: recompute it too. */
+                                  (implies that the call's last step prepares no continuation, like
+                                  CHS_STEP_LAST_CALL, unless CHS_STEP_KEEP_T1 is given too) */
+#define CHS_STEP_KEEP_T1 8     /* with CHS_STEP_REDERIVE_HAT: hat_U = dctn(U) is recomputed on entry, but the row
+                                  transform of EnergieEut(U) for the first step -- a function of the unchanged field
+                                  alone, which the last step of a completed predecessor left on the device as every
+                                  step inside a call does -- is taken over instead of being computed again (bit for
+                                  bit the same run); such a call's own last step prepares it for a successor */
 #define CHS_STEP_LAST_CALL 4   /* the run ends with this call: its last step does not prepare a continuation (the
                                   forward row pass of a step that will not come); a later call is still correct,
                                   it enters through hat_U = dctn(U) */

@@ -207,19 +207,19 @@ def test_calls_continue_the_device_loop(gpu, N, full_sim):
     U1, td1 = sol1.U.copy(), sol1.timedata.data().copy()
     one.close()
     runs = {}
-    # rederive 'full': the literal call with NOTHING taken over -- the residency is ended between the calls (chs_set_state),
-    # so every call enters through k_row_fwd2 (hat_U = dctn(U) and the row transform of EnergieEut(U) from one sweep of U);
+    # rederive 'full': the literal call with NOTHING taken over: every call enters through k_row_fwd2 (hat_U = dctn(U) and the
+    # row transform of EnergieEut(U) from one sweep of U) -- the default of rederive_hat;
     # rederive True: hat_U = dctn(U) recomputed, the first step's operand taken over from the previous call's last step
+    # (CHS_STEP_KEEP_T1, Solver.rederive_keeps_t1)
     for rederive in (False, True, 'full'):
         s = chsimpy_amd.Solver(make(N, nt, 'fast', full_sim=full_sim))
         s.rederive_hat = bool(rederive)
+        s.rederive_keeps_t1 = (rederive is True)
         s.prepare()
         o = orc.OracleSolver(orc.make_params(N, nt, full_sim=full_sim)) if N <= 128 else None
         if o:
             o.prepare()
         for c in chunks:
-            if rederive == 'full':
-                s._engine.set_state(s._engine.get_state())
             sol = s.solve_or_resume(c)
             if o:
                 o.solve_or_resume(c)

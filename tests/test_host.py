@@ -36,7 +36,7 @@ def test_header_constants_match_the_binding():
     """Every `#define CHS_<NAME> <integer>` of include/chs_hip.h that the ctypes binding mirrors has the same value there."""
     hdr = open(os.path.join(ROOT, 'include', 'chs_hip.h')).read()
     defs = {k: int(v, 0) for k, v in re.findall(r'#define\s+(CHS_[A-Z_0-9]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b', hdr)}
-    for name in ('CHS_STEP_CARRY_HAT', 'CHS_STEP_REDERIVE_HAT', 'CHS_STEP_LAST_CALL'):
+    for name in ('CHS_STEP_CARRY_HAT', 'CHS_STEP_REDERIVE_HAT', 'CHS_STEP_LAST_CALL', 'CHS_STEP_KEEP_T1'):
         assert name in defs, name
     mirrored = [k for k in defs if hasattr(_lib, k)]
     assert len(mirrored) >= 6
