@@ -70,7 +70,16 @@ template <> struct RowTwLds<F4096> { static constexpr int value = CHS_F4096_ROW_
 // k_col: CHS_COL_THREADS/128 of the 4 columns of a tile per workgroup
 // (paired 16-byte exchange items -- 27 instead of 39 barriers, 463 instead of 559 LDS instructions, 78 instead of 45 KB
 // of LDS -- measured equal: 4829 against 4829 steps/s over three interleaved rounds, profiles/r03_ab_xpair.txt)
+// CHS_F4096C_E32=1 (experiment, VERDICT round 3 item 1b, unrolled form): one wavefront per column, 32 values per lane, radices
+// 16.8.16 -- two exchanges instead of three, no workgroup barrier inside the passes (wave-local groups), 128-thread workgroups
+#ifndef CHS_F4096C_E32
+#define CHS_F4096C_E32 0
+#endif
+#if CHS_F4096C_E32
+using F4096C = FCfg<double, 4096, 64, 128, 16, 8, 1, 16, CHS_PAD1, CHS_PAD2, CHS_COL_PADL, CHS_COL_WPS, CHS_F4096_CT>;
+#else
 using F4096C = FCfg<double, 4096, 128, CHS_COL_THREADS, 8, 4, 8, 8, CHS_PAD1, CHS_PAD2, CHS_COL_PADL, CHS_COL_WPS, CHS_F4096_CT>;
+#endif
 // pass-0 twiddles: the k = 1 entries in LDS, the others as their powers (tw0_load<POW>): k_col 122-124 -> 119-121 us
 // against the whole table in LDS (profiles/r03_ab_tw2.txt); all from L2: 139 us
 #ifndef CHS_F4096C_TW_LDS

@@ -506,7 +506,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_fwd2(const typename 
         const T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
         // Ta is read once, by k_col<FWD_NATIVE> right behind this kernel: streamed like U (driver protocol 4471 -> 4533
         // steps/s, profiles/r03_ab_nt.txt); T1 is the first step's operand and stays cached
-        if (pass == 0) row_store<C, true>(dst, rw, pbase, launder(lr), idx, y);
+#ifndef CHS_FWD2_TA_NT
+#define CHS_FWD2_TA_NT 1
+#endif
+        if (pass == 0) row_store<C, (CHS_FWD2_TA_NT != 0)>(dst, rw, pbase, launder(lr), idx, y);
         else row_store<C>(dst, rw, pbase, launder(lr), idx, y);
       }
     }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
