@@ -1165,7 +1165,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
 
   // ---- recombination / spectral stage / adjoint recombination, in place per slot
   double e2 = 0.0;
-  constexpr bool MEAN_NOW = !PreAll<C>::value;
+#ifndef CHS_MEAN_NOW_ALL
+#define CHS_MEAN_NOW_ALL 0
+#endif
+  constexpr bool MEAN_NOW = !PreAll<C>::value || (CHS_MEAN_NOW_ALL != 0);
   [[maybe_unused]] T h00 = T(0);
   constexpr bool FWD = (MODE != MODE_INV_NATURAL && MODE != MODE_INV_NATIVE);
   constexpr bool ADJ = (MODE == MODE_STEP || MODE == MODE_INV_NATURAL || MODE == MODE_INV_NATIVE);
