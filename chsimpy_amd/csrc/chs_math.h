@@ -290,9 +290,18 @@ __device__ __forceinline__ T chs_spectral(T hatU, T hatMu, double li, double lj,
 #pragma clang fp contract(off)
   if constexpr (sizeof(T) == 4 && F32MATH) return chs_spectral_f32(hatU, hatMu, li, lj, lam1, lam2);
   const double leig = li + lj;
+#ifndef CHS_SPECTRAL_FMA
+#define CHS_SPECTRAL_FMA 0
+#endif
+#if CHS_SPECTRAL_FMA
+  // fused multiply-adds (one rounding less each than numpy's separate operations: differences of an ulp in hat_U)
+  const double CHeig = __builtin_fma(lam2 * leig, leig, 1.0);
+  const double rhs = __builtin_fma(lam1 * leig, (double)hatMu, (double)hatU);
+#else
   const double CHeig = 1.0 + (lam2 * leig) * leig;
   const double Seig = lam1 * leig;
   const double rhs = (double)hatU + Seig * (double)hatMu;
+#endif
   // CHeig >= 1: reciprocal + one Newton step + residual correction (the correction squares the
   // reciprocal's remaining error: < 1 ulp of the correctly rounded quotient, measured) instead of the
   // ~2.5x longer IEEE division sequence

@@ -254,3 +254,25 @@ def test_experiment_starts_its_own_8_ranks_and_the_files_do_not_depend_on_the_wo
     meta = open(str(tmp_path / 'w8-metadata.csv')).read()
     assert 'ranks, 8' in meta and 'dry_run, True' in meta and 'host_cores_per_rank' in meta
     assert 'Output files:' in r8.stdout            # rank 0's report is forwarded by the launching parent
+
+
+def test_experiment_as_ranks_of_torch_distributed_run(tmp_path):
+    """The other way in: `python -m torch.distributed.run --nproc-per-node 2 -m chsimpy_amd.experiment ...` (RANK / WORLD_SIZE
+    come from the launcher: no ranks of its own then), gloo + --dry-run on CPUs; rank 0 writes the files of a single rank."""
+    import subprocess
+    import pandas as pd
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e['PYTHONPATH'] = ROOT + os.pathsep + e.get('PYTHONPATH', '')
+    base = ['-N', '16', '-K', '3e-4', '-R', '7', '--dry-run', '--backend', 'gloo', '--gpus', '2']
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(_free_port()), '-m', 'chsimpy_amd.experiment', '--file-id', str(tmp_path / 't2')] + base,
+                       env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r1 = subprocess.run([sys.executable, '-m', 'chsimpy_amd.experiment', '--file-id', str(tmp_path / 't1')] + base[:-2],
+                        env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    a, b = pd.read_csv(str(tmp_path / 't2-results.csv'), index_col=0), pd.read_csv(str(tmp_path / 't1-results.csv'), index_col=0)
+    assert a.shape == (7, 12) and a.equals(b)
+    assert 'ranks, 2' in open(str(tmp_path / 't2-metadata.csv')).read()
