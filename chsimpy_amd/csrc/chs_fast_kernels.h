@@ -863,6 +863,11 @@ struct ColTwLds { static constexpr int value = 1; };
 // (tools/scratch_check.py: no spill in any k_col from N = 1024 upwards)
 template <class C>
 struct ColLamSgpr { static constexpr bool value = true; };
+// ... and whether the tile workgroups start with their loads (stop flag taken along with the first staging barrier, twiddle
+// copy requested in front of the first tile request and stored behind it) instead of two L2 round trips and a barrier in
+// front of them: where the extra registers held across the request do not spill (fp64 below N = 4096: 48-80 bytes)
+template <class C>
+struct ColLateStart { static constexpr bool value = (sizeof(typename C::T) == 4) || (C::N >= 4096); };
 template <class C>
 constexpr int col_tw_lds_elems() {
   if (ColTwLds<C>::value == 1) return 2 * ((C::R0 - 1) * C::L1 + (C::RA > 1 ? (C::RA - 1) * C::L2 : 0) + (C::RB > 1 ? (C::RB - 1) * C::L3 : 0));
@@ -886,14 +891,20 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   using T = typename C::T;
   using CS = ColStage<C>;
   __shared__ double red[32];
-  if constexpr (MODE == MODE_STEP) {
-    // block 0 of this very launch may raise the stop flag (the riding tail): one thread reads it for the whole
-    // workgroup, so that all its wavefronts leave or stay together
-    __shared__ int halted;
+  // MODE_STEP: block 0 of this very launch may raise the stop flag (the riding tail, a gate that timed out): one thread
+  // reads it for the whole workgroup, so that all its wavefronts leave or stay together.  EARLY_HALT: at the very top, in
+  // front of everything (a load, a barrier and an LDS round trip before the first tile load is even requested); otherwise
+  // the tile workgroups take the flag along with their first staging barrier -- nothing but loads has been issued by then.
+  __shared__ int halted;
+#ifndef CHS_COL_LATE_HALT
+#define CHS_COL_LATE_HALT 1
+#endif
+  constexpr bool LATE_HALT = (MODE == MODE_STEP) && (CHS_COL_LATE_HALT != 0) && ColLateStart<C>::value && !(ColDma<C>::value);
+  if constexpr (MODE == MODE_STEP && !LATE_HALT) {
     if (threadIdx.x == 0) halted = st->halt;
     __syncthreads();
     if (halted) return;
-  } else {
+  } else if constexpr (MODE != MODE_STEP) {
     if (st->halt) return;
   }
   if constexpr (MODE == MODE_STEP) STAMP(1, 0);
@@ -909,6 +920,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     if (ta.enabled) {
       const bool at_end = !ta.gate;
       if (bid == (at_end ? (int)gridDim.x - 1 : 0)) {
+        if constexpr (LATE_HALT) {   // (the bookkeeping workgroup keeps its check up front)
+          if (threadIdx.x == 0) halted = st->halt;
+          __syncthreads();
+          if (halted) return;
+        }
         step_tail_body<C::THREADS>(ta, st, reinterpret_cast<double*>(chs_dyn_lds));
         return;
       }
@@ -942,7 +958,32 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
   constexpr bool DMA = ColDma<C>::value && (MODE == MODE_STEP || MODE == MODE_FWD_NATIVE);
   static_assert(!DMA || (DmaStage<C>::OK && sizeof(T) == 8), "LDS-DMA stage-in: 16-byte row pieces of whole wavefronts");
   // (DMA: the twiddle copy is requested in front of the DMA pieces and stored behind their wait, below)
-  if constexpr (MODE == MODE_STEP && ColTwLds<C>::value != 0 && !DMA) {
+  // LATE_HALT (the register-staged path): the copy's loads are requested HERE and stored to LDS behind the request of
+  // the first half of the tile -- as a load/store loop in front of it, the copy was two L2 round trips in a row during
+  // which no tile load was in flight (~1.5 K cycles of a ~47 K-cycle workgroup life)
+  constexpr bool TW_SPLIT = LATE_HALT && (ColTwLds<C>::value != 0);
+  constexpr int TW_N0 = TW0POW ? 2 * C::L1 : 2 * (C::R0 - 1) * C::L1;
+  constexpr int TW_NM = col_tw_lds_elems<C>() - TW_N0;
+  constexpr int TW_I0 = (TW_N0 + 2 * C::THREADS - 1) / (2 * C::THREADS), TW_IM = (TW_NM + 2 * C::THREADS - 1) / (2 * C::THREADS);
+  using TwPair = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+  [[maybe_unused]] TwPair tws_a[TW_SPLIT ? TW_I0 : 1], tws_b[TW_SPLIT ? (TW_IM > 0 ? TW_IM : 1) : 1];
+  if constexpr (TW_SPLIT) {
+#pragma unroll
+    for (int i = 0; i < TW_I0; ++i) {
+      const int e = 2 * ((int)threadIdx.x + i * C::THREADS);
+      if (e < TW_N0) tws_a[i] = *reinterpret_cast<const TwPair*>(tb.tw0 + e);
+    }
+#pragma unroll
+    for (int i = 0; i < TW_IM; ++i) {
+      const int e = 2 * ((int)threadIdx.x + i * C::THREADS);
+      if (e < TW_NM) tws_b[i] = *reinterpret_cast<const TwPair*>(tb.twa + e);
+    }
+    T* ltw = lds + col_lds_elems<C>();
+    tbp.tw0 = ltw;
+    tbp.twa = ltw + TW_N0;
+    tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
+  }
+  if constexpr (MODE == MODE_STEP && ColTwLds<C>::value != 0 && !DMA && !TW_SPLIT) {
     T* ltw = lds + col_lds_elems<C>();
     // pass-0 part (the whole table, or its k = 1 entries), then twa | twb (contiguous behind tw0 in the table buffer)
     constexpr int N0 = TW0POW ? 2 * C::L1 : 2 * (C::R0 - 1) * C::L1;
@@ -1120,9 +1161,28 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       }
     };
     request(0);
+    if constexpr (TW_SPLIT) {
+      T* ltw = lds + col_lds_elems<C>();
+#pragma unroll
+      for (int i = 0; i < TW_I0; ++i) {
+        const int e = 2 * ((int)threadIdx.x + i * C::THREADS);
+        if (e < TW_N0) *reinterpret_cast<TwPair*>(ltw + e) = tws_a[i];
+      }
+#pragma unroll
+      for (int i = 0; i < TW_IM; ++i) {
+        const int e = 2 * ((int)threadIdx.x + i * C::THREADS);
+        if (e < TW_NM) *reinterpret_cast<TwPair*>(ltw + TW_N0 + e) = tws_b[i];
+      }
+    }
+    if constexpr (LATE_HALT) {
+      if (threadIdx.x == 0) halted = st->halt;
+    }
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
       __syncthreads();
+      if constexpr (LATE_HALT) {
+        if (rho == 0 && halted) return;   // (uniform: every thread reads the same LDS word behind the barrier)
+      }
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int f = PW * (threadIdx.x + i * C::THREADS);
