@@ -317,6 +317,79 @@ __device__ __forceinline__ FTables<typename C::T> row_twiddles_to_lds(const FTab
   return tbp;
 }
 
+// The same copy in two halves -- `request` at the very top of a kernel (loads into registers), `store` behind the first
+// loads of the kernel's own first phase: as one load/store loop the copy was an L2 round trip during which nothing else of
+// the workgroup was in flight (the log table of the fused row kernel likewise: two round trips in a row, ~1.5 K cycles).
+// One iteration per thread wherever the tables fit 2 * THREADS elements per part (N >= 4096); the kernels fall back to the
+// loop otherwise (RowTwSplit).
+template <class C>
+struct RowTwSplit {
+  static constexpr int RTWM = RowTwLds<C>::value;
+  static constexpr int N0 = (RTWM == 2) ? 2 * C::L1 : (RTWM == 1 ? 2 * (C::R0 - 1) * C::L1 : 0);
+  static constexpr int NM = row_tw_lds_elems<C>() - N0;
+  static constexpr int I0 = (N0 + 2 * C::THREADS - 1) / (2 * C::THREADS), IM = (NM + 2 * C::THREADS - 1) / (2 * C::THREADS);
+  static constexpr bool value = (RTWM != 0) && (I0 + IM <= 2) && (C::THREADS >= CHS_LOGTAB_N);
+  using Pair = typename std::conditional<sizeof(typename C::T) == 8, double2, v2f>::type;
+  Pair a[I0 > 0 ? I0 : 1], b[IM > 0 ? IM : 1];
+  double2 lt;   // the log-table entry of this thread (fp64 kernels with a pointwise part)
+};
+template <class C, bool LOGTAB>
+__device__ __forceinline__ RowTwSplit<C> row_tables_request(const FTables<typename C::T>& tb, int tid) {
+  using S = RowTwSplit<C>;
+  using P = typename S::Pair;
+  RowTwSplit<C> r;   // (every member written on every path: the structure stays in registers)
+  r.a[0] = P{}; r.b[0] = P{}; r.lt = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int i = 0; i < S::I0; ++i) {
+    const int e = 2 * (tid + i * C::THREADS);
+    P v = P{};
+    if (e < S::N0) v = *reinterpret_cast<const P*>(tb.tw0 + e);
+    r.a[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < S::IM; ++i) {
+    const int e = 2 * (tid + i * C::THREADS);
+    P v = P{};
+    if (e < S::NM) v = *reinterpret_cast<const P*>(tb.twa + e);
+    r.b[i] = v;
+  }
+  if constexpr (LOGTAB) {
+    if (tid < CHS_LOGTAB_N) r.lt = reinterpret_cast<const double2*>(chs_log_table)[tid];
+  }
+  return r;
+}
+template <class C, bool LOGTAB>
+__device__ __forceinline__ void row_tables_store(int tid, const RowTwSplit<C>& r) {
+  using S = RowTwSplit<C>;
+  using T = typename C::T;
+  T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16);
+#pragma unroll
+  for (int i = 0; i < S::I0; ++i) {
+    const int e = 2 * (tid + i * C::THREADS);
+    if (e < S::N0) *reinterpret_cast<typename S::Pair*>(ltw + e) = r.a[i];
+  }
+#pragma unroll
+  for (int i = 0; i < S::IM; ++i) {
+    const int e = 2 * (tid + i * C::THREADS);
+    if (e < S::NM) *reinterpret_cast<typename S::Pair*>(ltw + S::N0 + e) = r.b[i];
+  }
+  if constexpr (LOGTAB) {
+    double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
+    if (tid < CHS_LOGTAB_N) ltab[tid] = r.lt;
+  }
+}
+template <class C>
+__device__ __forceinline__ FTables<typename C::T> row_tables_in_lds(const FTables<typename C::T>& tb) {
+  using S = RowTwSplit<C>;
+  using T = typename C::T;
+  FTables<T> tbp = tb;
+  T* ltw = reinterpret_cast<T*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T) + CHS_LOGTAB_N * 16);
+  if constexpr (S::N0 != 0) tbp.tw0 = ltw;
+  tbp.twa = ltw + S::N0;
+  tbp.twb = tbp.twa + (C::RA > 1 ? 2 * (C::RA - 1) * C::L2 : 0);
+  return tbp;
+}
+
 // Returns x through an opaque asm so that index arithmetic derived from it is not CSE'd
 // with (and kept alive since) an earlier phase of the kernel: recomputing a few integer
 // offsets is far cheaper than holding dozens of address registers across a phase.
@@ -546,14 +619,28 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
   const double mean_u = st->meanU;  // requested at entry (k_col of this step wrote it), used in the pointwise part
   // reduction table of the table-driven log, behind the exchange scratch (visible after the first barrier)
   double2* ltab = reinterpret_cast<double2*>(chs_dyn_lds + (size_t)C::C * C::SCR * sizeof(T));
-  if constexpr (DIAG && sizeof(T) == 8) {
+#ifndef CHS_ROW_TABLES_SPLIT
+#define CHS_ROW_TABLES_SPLIT 1
+#endif
+  // (SPLIT: the table copies are requested here and stored behind the first phase's loads, below)
+  // (measured: N=8192 fp64 +0.9 %, N=4096 fp64 equal, N=4096 fp32 -0.8 %, N=8192 fp32 -5 %: four row workgroups of a CU
+  // cover each other's round trips, and the registers held across the first phase cost the fp32 kernels more)
+  constexpr bool SPLIT = (CHS_ROW_TABLES_SPLIT != 0) && RowTwSplit<C>::value && !C::WAVE_LOCAL && sizeof(T) == 8 && C::N >= 8192;
+  constexpr bool LOGT = DIAG && sizeof(T) == 8;
+  [[maybe_unused]] RowTwSplit<C> tabs;
+  if constexpr (SPLIT) {
+    tabs = row_tables_request<C, LOGT>(tb, wv * 64 + chs_lane_id());
+  } else if constexpr (LOGT) {
     for (int t = wv * 64 + chs_lane_id(); t < CHS_LOGTAB_N; t += C::THREADS) ltab[t] = reinterpret_cast<const double2*>(chs_log_table)[t];
   }
   // pass twiddles from LDS where the configuration has room (RowTwLds): visible behind the first exchange barrier of
   // the inverse passes, whose last-pass butterflies come first and need none
   constexpr int RTWM = RowTwLds<C>::value;
   constexpr bool RTW = (RTWM == 2);   // pass-0 twiddles by powers
-  const FTables<T> tbp = row_twiddles_to_lds<C>(tb, wv * 64 + chs_lane_id());
+  FTables<T> tbp_ = tb;
+  if constexpr (SPLIT) tbp_ = row_tables_in_lds<C>(tb);
+  else tbp_ = row_twiddles_to_lds<C>(tb, wv * 64 + chs_lane_id());
+  const FTables<T> tbp = tbp_;
   // (groups inside one wavefront exchange behind wavefront fences only: no block barrier would make the log table and
   // the twiddles visible before their first use)
   if constexpr (C::WAVE_LOCAL && ((DIAG && sizeof(T) == 8) || RTWM != 0)) __syncthreads();
@@ -577,6 +664,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
     Ya = cx_make(p.y[0], p.y[1]); Yb = cx_make(p.y[2], p.y[3]);
   }, [](int, const int*, Cx<T>&, Cx<T>&, bool) {});
   if constexpr (DIAG && FUSE) STAMP(0, 1);
+  if constexpr (SPLIT) row_tables_store<C, LOGT>(wv * 64 + chs_lane_id(), tabs);   // (visible behind the first exchange barrier)
   inv_passes<C, RTW>(z, scr, tbp, row_l<C>(wv, l));
   if constexpr (DIAG && FUSE) STAMP(0, 2);
   __builtin_amdgcn_sched_barrier(0);  // phase fence: nothing of the next phase is hoisted up here
