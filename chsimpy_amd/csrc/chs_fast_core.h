@@ -500,8 +500,12 @@ __device__ __forceinline__ void tw0_load(const typename C::T* tw0, int m, typena
 }
 
 // Forward: pass-0 operands in -> last-pass outputs Z out (index ((q*2+b)*RL + k)).
-template <class C, bool TW0POW = false>
-__device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr, const FTables<typename C::T>& tb, int l) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `before_last()` runs right in front of the last-pass butterflies (behind the last exchange): the place to request what the
+// stage behind the transform needs first, so that its round trip runs under those butterflies
+template <class C, bool TW0POW = false, class HOOK = NoHook>
+__device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr, const FTables<typename C::T>& tb, int l,
+                                           HOOK&& before_last = HOOK()) {
   using T = typename C::T;
   using V = typename C::V;
   // ---- pass 0: radix R0 on every owned butterfly, then twiddle by omega_M^(m k)
@@ -533,6 +537,7 @@ __device__ __forceinline__ void fwd_passes(typename C::V* z, typename C::T* scr,
     CHS_EXCHANGE(mv_pass0, mv_last);
   }
   // ---- last pass
+  before_last();
 #pragma unroll
   for (int q = 0; q < 2 * C::NP2; ++q) Dft<V, C::RL, false>::run(z + q * C::RL);
 }
@@ -607,12 +612,17 @@ __device__ __forceinline__ int fc_opaque(int x) {
 // round trip to L2 that nothing hides (N=512: 4-5 round trips in a row per kernel); the registers are there.
 template <class C>
 struct PreAll { static constexpr bool value = (C::E <= 8); };
-template <class C, bool FWD, bool ADJ, bool PIPE_, class PRE, class F, class ST>
-__device__ __forceinline__ void recombine(typename C::V* z, const FTables<typename C::T>& tb, int l, PRE&& pre, F&& f, ST&& st) {
+// (recombine's last parameter: something the caller requested ahead of the stage for the first slot of pair 0; its
+// `patch(fetched)` puts it in place of what the slot's own request would bring -- the compiler drops that part of the request)
+struct NoSlot0 {};
+template <class C, bool FWD, bool ADJ, bool PIPE_, class PRE, class F, class ST, class S0 = NoSlot0>
+__device__ __forceinline__ void recombine(typename C::V* z, const FTables<typename C::T>& tb, int l, PRE&& pre, F&& f, ST&& st,
+                                          const S0* ext0 = nullptr) {
   using T = typename C::T;
   using V = typename C::V;
   constexpr bool PREALL = PreAll<C>::value;
   constexpr bool PIPE = PIPE_ && !PREALL;
+  constexpr bool EXT0 = PIPE && !std::is_same<S0, NoSlot0>::value;   // part of pair 0's first request was made by the caller
   constexpr int R2 = C::R2, N = C::N, M = C::M, H = R2 / 2;
   const V zero = cx_make(T(0), T(0));
 #pragma unroll
@@ -635,6 +645,7 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
       if constexpr (PIPE) {
         wn = slot_tw<T>(tb, kap);
         pn = pre(q * R2 * 4, id0);
+        if constexpr (EXT0) { if (q == 0) ext0->patch(pn); }
       }
       if constexpr (PREALL) {
 #pragma unroll
@@ -702,6 +713,7 @@ __device__ __forceinline__ void recombine(typename C::V* z, const FTables<typena
       if constexpr (PIPE) {  // slot 0 of the loop below, requested ahead of the special lane's own slot
         wn = slot_tw<T>(tb, o1);
         pn = pre(q * R2 * 4, id0);
+        if constexpr (EXT0) ext0->patch(pn);   // (the special pair is pair 0: q == 0 here)
         if (sp) whp = slot_tw<T>(tb, M / 2);  // the special lane's second self-paired butterfly
       }
       if constexpr (PREALL) {

@@ -954,6 +954,18 @@ struct ColLamSgpr { static constexpr bool value = true; };
 // ... and whether the tile workgroups start with their loads (stop flag taken along with the first staging barrier, twiddle
 // copy requested in front of the first tile request and stored behind it) instead of two L2 round trips and a barrier in
 // front of them: where the extra registers held across the request do not spill (fp64 below N = 4096: 48-80 bytes)
+#ifndef CHS_COL_PIPE
+#define CHS_COL_PIPE 1   // 0: the spectral stage fetches slot k in slot k (fewer live registers; measured, DESIGN.md)
+#endif
+#ifndef CHS_COL_PRE0
+#define CHS_COL_PRE0 0   // (measured: fp32 within +-0.5 %, fp64 -- with the coefficients left in VGPRs to avoid scratch -- 2.4 % slower)
+#endif
+#ifndef CHS_COL_PRE0_F64
+#define CHS_COL_PRE0_F64 0   // (fp64 at its 256 registers: 20-28 bytes of scratch with it, unless the coefficients stay in VGPRs)
+#endif
+// ... and whether the spectral stage's first request goes out in front of the last forward pass (k_col: PRE0)
+template <class C>
+struct ColPre0 { static constexpr bool value = (CHS_COL_PRE0 != 0) && (sizeof(typename C::T) == 4 || (CHS_COL_PRE0_F64 != 0 && C::N >= 4096)); };
 template <class C>
 struct ColLateStart { static constexpr bool value = (sizeof(typename C::T) == 4) || (C::N >= 4096); };
 template <class C>
@@ -1126,6 +1138,16 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     p.h23 = ldc_hint<T, HAT_NT_LD>(hcol, hp + C::G);
     return p;
   };
+  // The spectral stage's first request (slot 0 of pair 0: twiddles, hat_U, eigenvalues) goes out in front of the LAST forward
+  // pass instead of behind it: its round trip (hat_U comes from the Infinity Cache) runs under that pass's butterflies
+  // (ColPre0; where a lane owns one pair, E = 2 RL, and the stage is pipelined)
+  constexpr bool PRE0 = (MODE == MODE_STEP) && ColPre0<C>::value && !DMA && !PreAll<C>::value && (CHS_COL_PIPE != 0) && (C::NP2 == 1);
+  // (hat_U alone: it is what comes from furthest away; the whole request held across the pass spilled 20-40 bytes in fp64)
+  struct HatPre {
+    Cx<T> h01, h23;
+    __device__ __forceinline__ void patch(Fetched& p) const { p.h01 = h01; p.h23 = h23; }
+  };
+  [[maybe_unused]] HatPre s0;
   if constexpr (DMA) {
     // ---- stage in by LDS-DMA: all pieces of both halves of the tile (NDMA per wavefront and half) are requested here,
     // in front of them the (compiler-visible) loads of the pass twiddles; one wait covers everything (vector-memory
@@ -1298,7 +1320,12 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     }
     __syncthreads();
     if constexpr (MODE == MODE_STEP) STAMP(1, 1);
-    fwd_passes<C, TW0POW>(z, scr, tbp, l);
+    if constexpr (PRE0) fwd_passes<C, TW0POW>(z, scr, tbp, l, [&]() {
+      const int hp = hat_pair_index<C>(0, fc_opaque(l));
+      s0.h01 = ldc_hint<T, HAT_NT_LD>(hcol, hp);
+      s0.h23 = ldc_hint<T, HAT_NT_LD>(hcol, hp + C::G);
+    });
+    else fwd_passes<C, TW0POW>(z, scr, tbp, l);
     if constexpr (MODE == MODE_STEP) STAMP(1, 2);
     if constexpr (MODE == MODE_STEP) {
       // Gated tail: the bookkeeping of the previous step -- stop rules, adaptive time step -- runs as block 0
@@ -1335,10 +1362,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     }
     // fp32: the coefficients of this launch as floats (after the gate: lam1/lam2 are this step's)
     [[maybe_unused]] const float lam1f = (float)lam1, lam2f = (float)lam2, lcf = (float)lc, sqcf = (float)sqc;
-#ifndef CHS_COL_PIPE
-#define CHS_COL_PIPE 1   // 0: the spectral stage fetches slot k in slot k (fewer live registers; measured, DESIGN.md)
-#endif
-    recombine<C, true, true, (CHS_COL_PIPE != 0)>(z, tb, l, fetch,
+    auto spec_f =
       [&](int pbase, const int*, Cx<T>& Ya, Cx<T>& Yb, bool live, const Fetched& p) {
         if constexpr (sizeof(T) == 8) {
           T y[4] = {cx_re(Ya), cx_im(Ya), cx_re(Yb), cx_im(Yb)};
@@ -1380,14 +1404,17 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
           if constexpr (MEAN_NOW) { if (pbase == 0 && live && l == 0 && kc == 0) st->meanU = (double)Ya.x / (double)C::N; }  // (as in fp64 above)
           else if (pbase == 0 && live) h00 = Ya.x;
         }
-      },
+      };
+    auto spec_st =
       [&](int pbase, const int*, Cx<T>& Ya, Cx<T>& Yb, bool live) {
         if (live) {
           const int hp = hat_pair_index<C>(pbase, fc_opaque(l));
           stc_hint<T, HAT_NT_ST>(hout, hp, Ya);
           stc_hint<T, HAT_NT_ST>(hout, hp + C::G, Yb);
         }
-      });
+      };
+    if constexpr (PRE0) recombine<C, true, true, (CHS_COL_PIPE != 0)>(z, tb, l, fetch, spec_f, spec_st, &s0);
+    else recombine<C, true, true, (CHS_COL_PIPE != 0)>(z, tb, l, fetch, spec_f, spec_st);
     if constexpr (sizeof(T) == 4) e2 = (double)e2v.x + (double)e2v.y;
   } else {
     recombine<C, FWD, ADJ, false>(z, tb, l, [](int, const int*) { return NoFetch{}; },

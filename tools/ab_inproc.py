@@ -2,7 +2,9 @@
 """A/B timing of library variants INSIDE ONE PROCESS: every variant (chsimpy_amd/lib/variants/*.so, or paths given)
 is loaded side by side through its own ctypes binding, gets its own engine on the same GPU, and the timed calls
 alternate A, B, C, A, B, C, ... back to back -- same box, same thermal / power state, no process start between them.
-Resolves differences of a few tenths of a per cent, where one process per variant (tools/ab.sh) has +-1.5 % of noise.
+Run-to-run spread is a few tenths of a per cent (one process per variant, tools/ab.sh: +-1.5 %); but WHERE an engine's buffers
+land in memory is worth up to ~1.2 % between identical libraries -- use --copies 2..3 and/or both creation orders (--reverse)
+before believing a difference below ~1.5 %.
 
     python tools/ab_inproc.py [--grid 4096] [--dtype float64] [--steps 300] [--rounds 12] [--mode literal|continue|adaptive]
                               [--glob 'a_*'] [paths...]
@@ -48,15 +50,22 @@ def main():
     ap.add_argument('--mode', default='continue', choices=['literal', 'continue', 'adaptive', 'estop'])
     ap.add_argument('--delt-max', type=float, default=None)
     ap.add_argument('--glob', default='*')
+    ap.add_argument('--copies', type=int, default=1, help='engines per variant, created interleaved (a b c a b c ...): where an engine\'s buffers land in memory is worth up to ~1.2 %% between IDENTICAL libraries; several engines per variant average that out')
+    ap.add_argument('--reverse', action='store_true', help='create the engines in reverse order (buffer placement differs by engine: a ratio that flips with the order is placement, not code)')
     ap.add_argument('--profile', type=int, default=0, help='afterwards: per-kernel device time (HIP events) over this many steps, per variant')
     ap.add_argument('paths', nargs='*')
     a = ap.parse_args()
     paths = a.paths or sorted(glob.glob(os.path.join(ROOT, 'chsimpy_amd', 'lib', 'variants', a.glob + '.so')))
     assert paths, 'no variants'
+    if a.reverse:
+        paths = paths[::-1]
     import chsimpy_amd
     engines = []
-    for i, path in enumerate(paths):
-        mod = bind(os.path.abspath(path), str(i))
+    mods = {}
+    for i, path in enumerate(paths * a.copies):
+        if path not in mods:
+            mods[path] = bind(os.path.abspath(path), str(i))
+        mod = mods[path]
         p = chsimpy_amd.Parameters()
         p.N, p.ntmax, p.full_sim, p.kappa_tilde, p.dtype, p.engine = a.grid, 10 ** 9, a.mode != 'estop', KAPPA, a.dtype, 'fast'
         if a.mode == 'adaptive':
@@ -75,7 +84,7 @@ def main():
         assert rc == 0, (path, rc)
         engines.append((os.path.basename(path)[:-3], eng))
     kw = dict(rederive_hat=True, last_call=False) if a.mode == 'literal' else {}
-    ms = {n: [] for n, _ in engines}
+    ms = {n: [] for n, _ in engines}      # (several engines of one variant share a name: their times are pooled)
     wall = {n: [] for n, _ in engines}
     for r in range(a.rounds):
         order = engines if r % 2 == 0 else engines[::-1]     # (alternate the order: nobody always runs behind the same one)
@@ -85,9 +94,13 @@ def main():
             wall[n].append((time.perf_counter() - t0) * 1e3 / a.steps)
             assert rc == 0 and rows.shape[0] == a.steps, (n, rc, rows.shape)
             ms[n].append(eng.last_step_ms() / a.steps)
-    ref = engines[0][0]
-    print(f"# N={a.grid} {a.dtype} mode={a.mode} steps/call={a.steps} rounds={a.rounds} (device ms per step; ratio = variant / {ref}, per round)")
+    ref = engines[-1][0] if a.reverse else engines[0][0]
+    names = []
     for n, _ in engines:
+        if n not in names:
+            names.append(n)
+    print(f"# N={a.grid} {a.dtype} mode={a.mode} steps/call={a.steps} rounds={a.rounds} copies={a.copies} (device ms per step; ratio = variant / {ref}, per round)")
+    for n in names:
         ratios = [x / y for x, y in zip(ms[n], ms[ref])]
         print(f"{n:28s} median {statistics.median(ms[n]):.5f}  min {min(ms[n]):.5f}  wall median {statistics.median(wall[n]):.5f}  "
               f"ratio median {statistics.median(ratios):.4f}  [{min(ratios):.4f} .. {max(ratios):.4f}]  "
