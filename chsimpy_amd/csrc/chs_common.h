@@ -235,6 +235,7 @@ struct Engine {
   void* dT1 = nullptr;     // transform scratch
   void* dT2 = nullptr;     // transform scratch
   void* dHat = nullptr;    // hat_U (direct: natural order; fast: engine-native order)
+  void* dSlab = nullptr;   // one allocation holding dT1 | dHat (chs_create)
   void* dHat2 = nullptr;   // second hat_U buffer of the small grids' stop-rule runs (chs_fast_step), allocated on demand
   void* dHatCall = nullptr;  // ... the buffer hat_U was in when the running call began
   bool hatFlip = false;    // ... this call alternates the two

@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--mode', default='continue', choices=['literal', 'continue', 'adaptive', 'estop'])
     ap.add_argument('--delt-max', type=float, default=None)
     ap.add_argument('--glob', default='*')
+    ap.add_argument('--envs', default='', help="';'-separated environment settings, each 'K=V[,K=V]': every variant gets one engine per setting (set while the engine is created), e.g. 'CHS_SLAB=0;CHS_SLAB=1'")
     ap.add_argument('--copies', type=int, default=1, help='engines per variant, created interleaved (a b c a b c ...): where an engine\'s buffers land in memory is worth up to ~1.2 %% between IDENTICAL libraries; several engines per variant average that out')
     ap.add_argument('--reverse', action='store_true', help='create the engines in reverse order (buffer placement differs by engine: a ratio that flips with the order is placement, not code)')
     ap.add_argument('--profile', type=int, default=0, help='afterwards: per-kernel device time (HIP events) over this many steps, per variant')
@@ -62,10 +63,17 @@ def main():
     import chsimpy_amd
     engines = []
     mods = {}
-    for i, path in enumerate(paths * a.copies):
+    envs = [e for e in a.envs.split(';') if e] or ['']
+    todo = [(path, env) for path in paths for env in envs] * a.copies
+    for i, (path, env) in enumerate(todo):
         if path not in mods:
             mods[path] = bind(os.path.abspath(path), str(i))
         mod = mods[path]
+        saved = {}
+        for kv in [x for x in env.split(',') if x]:
+            k, v = kv.split('=', 1)
+            saved[k] = os.environ.get(k)
+            os.environ[k] = v
         p = chsimpy_amd.Parameters()
         p.N, p.ntmax, p.full_sim, p.kappa_tilde, p.dtype, p.engine = a.grid, 10 ** 9, a.mode != 'estop', KAPPA, a.dtype, 'fast'
         if a.mode == 'adaptive':
@@ -82,7 +90,12 @@ def main():
         eng.prepare()
         rows, rc = eng.step_n(max(a.warm, 520 if a.mode == 'adaptive' else 0))
         assert rc == 0, (path, rc)
-        engines.append((os.path.basename(path)[:-3], eng))
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+        engines.append((os.path.basename(path)[:-3] + (' ' + env if env else ''), eng))
     kw = dict(rederive_hat=True, last_call=False) if a.mode == 'literal' else {}
     ms = {n: [] for n, _ in engines}      # (several engines of one variant share a name: their times are pooled)
     wall = {n: [] for n, _ in engines}
