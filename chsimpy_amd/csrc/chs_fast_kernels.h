@@ -810,20 +810,21 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_row_inv(const typename C
                 unpack_quads<C>(z, q, j, q1, q2);  // mu of row `row`, columns 4*(m + L1*j) .. +3
                 const int c1 = 4 * (m1 + C::L1 * j), c2 = 4 * (m2 + C::L1 * j);
                 const int o1 = c1 - h * (C::N / NH), o2 = c2 - h * (C::N / NH);
+                T g1[4], g2[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  T g1 = chs_dt_integrand_fast(q1[e], dmax);
-                  T g2 = chs_dt_integrand_fast(q2[e], dmax);
-                  if (s < C::C - 1) { g1 += gl[o1 + e]; g2 += gl[o2 + e]; }
-                  if (s > 0) { gl[o1 + e] = g1; gl[o2 + e] = g2; }
-                  else if constexpr (chs_grid_exceeds_cache(C::N, sizeof(T))) {
-                    // written once, read once by the reduction kernels: streamed where the grid does not fit the cache
-                    // (N=8192 fp32 adaptive 1893 -> 1925 steps/s; N=4096 fp64, where it fits, 4119 -> 3974 if streamed)
-                    __builtin_nontemporal_store(g1, &prow[c1 + e]);
-                    __builtin_nontemporal_store(g2, &prow[c2 + e]);
-                  } else {
-                    prow[c1 + e] = g1; prow[c2 + e] = g2;
-                  }
+                  g1[e] = chs_dt_integrand_fast(q1[e], dmax);
+                  g2[e] = chs_dt_integrand_fast(q2[e], dmax);
+                  if (s < C::C - 1) { g1[e] += gl[o1 + e]; g2[e] += gl[o2 + e]; }
+                  if (s > 0) { gl[o1 + e] = g1[e]; gl[o2 + e] = g2[e]; }
+                }
+                if (s == 0) {
+                  // the quad's four columns are contiguous in the partial row: ONE 16-byte store per element pair/quad (element
+                  // by element the non-temporal stores stayed 4-byte instructions: 64 of them per thread at N=8192 fp32).
+                  // Written once, read once by the reduction kernels: streamed where the grid does not fit the cache
+                  // (N=8192 fp32 adaptive 1893 -> 1925 steps/s; N=4096 fp64, where it fits, 4119 -> 3974 if streamed)
+                  if constexpr (chs_grid_exceeds_cache(C::N, sizeof(T))) { store4_nt<T>(&prow[c1], g1); store4_nt<T>(&prow[c2], g2); }
+                  else { store4<T>(&prow[c1], g1); store4<T>(&prow[c2], g2); }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one quad pair at a time: no pile-up of addresses and operands
               }
@@ -1482,7 +1483,15 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
           *reinterpret_cast<chs_f4v*>(dst) = v;
         } else {
           const T a = lds[lo], b = lds[lo + 1];
-          if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(a, b);
+#ifndef CHS_COL_OUT_POLICY
+#define CHS_COL_OUT_POLICY 0   // experiment: cache policy of k_col's T stores: 0 plain, 1 sc1 (write-through), 2 nt, 3 sc0 sc1
+#endif
+          if constexpr (sizeof(T) == 8 && CHS_COL_OUT_POLICY != 0 && MODE == MODE_STEP) {
+            chs_d2v v; v.x = a; v.y = b;
+            if constexpr (CHS_COL_OUT_POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+            else if constexpr (CHS_COL_OUT_POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(v) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
+          } else if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(a, b);
           else *reinterpret_cast<float2*>(dst) = make_float2(a, b);
         }
       }
