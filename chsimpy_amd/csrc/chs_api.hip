@@ -435,6 +435,7 @@ extern "C" int chs_set_state(chs_handle h, const chs_state* in) {
   s.skip_check = in->skip_check; s.stop_reason = in->stop_reason;
   // (the coefficients follow params.delt, not this delt: every call reloads them, k_call_begin)
   CHS_HIP(hipMemcpy(E->dState, &s, sizeof s, hipMemcpyHostToDevice));
+  E->csHost = s.computed_steps;
   return CHS_OK;
 }
 
@@ -453,6 +454,7 @@ extern "C" int chs_prepare(chs_handle h, double row0[9]) {
   CHS_HIP(hipStreamSynchronize(E->stream));
   CHS_HIP(hipMemcpy(row0, E->dRows, sizeof(double) * 9, hipMemcpyDeviceToHost));
   E->prepared = true;
+  E->csHost = 1;   // (solver.py:128-135: computed_steps = 1 behind the step-0 record)
   for (int i = 0; i < 9; ++i)
     if (row0[i] != row0[i]) { chs_set_error("chs_prepare: NaN in the step-0 record (timedata.py:10)"); return CHS_ENAN; }
   return CHS_OK;
@@ -628,7 +630,7 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
     // the next chs_step_n returns CHS_ESTATE until chs_set_U / chs_init_U_pcg64 and chs_prepare have run.
     E->hat_valid = false; E->resident = false; E->stateCached = false;
     E->tailDeferred = false; E->tailGated = false;
-    E->prepared = false; E->have_U = false;
+    E->prepared = false; E->have_U = false; E->csHost = -1;
     if (steps_done) *steps_done = 0;
     chs_set_error("internal: a workgroup gave up waiting for the step's bookkeeping (gated tail)");
     return CHS_EHIP;
@@ -656,6 +658,7 @@ static int run_steps(Engine* E, int64_t nsteps, int flags, double* rows, int64_t
   if (s.halt) E->hat_valid = false;  // (a deferred tail lets k_col run once past a NaN stop)
   if (nsteps > 0) E->resident = E->keepResident && !s.halt && s.rows_written >= nsteps;
   E->stateCached = true;  // (the recovery above leaves the device state equal to s)
+  E->csHost = s.computed_steps;
   int64_t done = s.rows_written;
   if (done > nsteps) done = nsteps;
   if (steps_done) *steps_done = done;

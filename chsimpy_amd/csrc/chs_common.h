@@ -226,6 +226,10 @@ struct Engine {
   bool hat_valid = false;  // dHat matches dU's history (CHS_STEP_CARRY_HAT)
   bool resident = false;   // ... and T1 / partMu hold the row transform of EnergieEut(U) and its sum of squares: the
                            // next call continues without an entry pass (the last fused step left them, chs_fast_step)
+  bool adaptSparse = true;    // CHS_ADAPT_SPARSE (chs_fast_rearm)
+  long long csHost = -1;      // the device's computed_steps as the host can follow it (prepare / set_state / end of a call, +1 per
+                              // issued step): lets the adaptive path issue the step-size machinery only on the steps whose rule
+                              // fires (chs_fast_step); -1 = not known
   bool stateCached = false;   // hState[0] is the device state as the last call left it (chs_get_state without a round trip)
   bool keepResident = false;  // this call's last step runs the fused row kernel so that the next call can continue
 

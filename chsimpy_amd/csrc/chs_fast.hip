@@ -119,6 +119,7 @@ int chs_fast_init(Engine* E) {
 // is taken into use again (chs_create).
 int chs_fast_rearm(Engine* E) {
   E->fusedAdapt = E->adaptOk && getenv("CHS_ADAPT_SWEEP") == nullptr;
+  { const char* e = getenv("CHS_ADAPT_SPARSE"); E->adaptSparse = !(e && e[0] == '0'); }   // (read when an engine is taken into use)
   if (E->dc.adaptive_time && E->fusedAdapt && !E->dPartColRows)
     CHS_HIP(hipMalloc(&E->dPartColRows, E->esz * (size_t)E->nRowBlocks * E->N));
   if (E->partSet[0][0]) {
@@ -308,6 +309,17 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   if (rc) return rc;
   chs_slot_begin(E, SLOT_INV);
   const bool fa = fused_adaptive(E);
+  // Adaptive step with the host able to follow the step counter: the step-size rule fires on every second step beyond
+  // step 500 only (solver.py:177), and only THOSE steps need the column sums reduced and the next k_col gated (its
+  // coefficients change).  On the others -- with nothing else armed that a tail could decide -- the reduction launches are
+  // not issued at all (they used to return at once: two empty launches per step) and the bookkeeping rides ungated.
+  // (CHS_ADAPT_SPARSE=0: as before round 4.)
+  bool fires = true;
+  if (E->dc.adaptive_time && E->csHost >= 0 && E->adaptSparse) {
+    const long long cs_next = E->csHost + 1;          // the counter behind this step's record (chs_tail.h: cs_next)
+    fires = (cs_next > 500 && (cs_next % 2) == 0);
+  }
+  if (E->csHost >= 0) E->csHost += 1;                 // (a halted run issues no-ops; the call's end sets the true value)
   if (last && E->keepResident) {
     // the last step of the call leaves the field in HBM like ROW_INV_DIAG, and with it what the first column
     // pass of a following call needs (T1, sum(mu^2)): that call then starts without an entry pass (run_steps)
@@ -320,7 +332,7 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   }
   chs_slot_end(E, SLOT_INV);
   if (rc) return rc;
-  if (!last && E->dc.adaptive_time) {
+  if (!last && E->dc.adaptive_time && (fires || !fa)) {
     // column sums of the adaptive-step integrand of the NEXT step (solver.py:183); the record of
     // this step has not advanced computed_steps yet, hence the offset
     if ((rc = fa ? chs_launch_colmin_rows(E, 1) : chs_launch_mu_colsums(E, 1))) return rc;
@@ -330,8 +342,10 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   // tail, gate_wait) -- no 14 us one-block launch per step.  A run being profiled keeps the separate launch.
   const bool gate = !defer && !E->timer.on && E->partSet[0][0] != nullptr;
   if (last || (!defer && !gate)) return chs_launch_step_tail(E, last ? 0 : 1);
+  // (an adaptive step whose rule does not fire decides nothing the next k_col needs, unless a stop rule is armed)
+  const bool quiet = !fires && fa && E->dc.full_sim && !(E->dc.time_limit_s > 0.0);
   E->tailDeferred = true;
-  E->tailGated = gate;
+  E->tailGated = gate && !quiet;
   E->tailSet = E->parity;
   E->parity ^= 1;
   return CHS_OK;
