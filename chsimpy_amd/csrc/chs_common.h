@@ -226,6 +226,8 @@ struct Engine {
   bool hat_valid = false;  // dHat matches dU's history (CHS_STEP_CARRY_HAT)
   bool resident = false;   // ... and T1 / partMu hold the row transform of EnergieEut(U) and its sum of squares: the
                            // next call continues without an entry pass (the last fused step left them, chs_fast_step)
+  bool gateEarly = false;     // CHS_GATE_EARLY=1 (chs_fast_rearm): experiment, measured equal
+  bool tailEarly = false;     // the gated bookkeeping of the coming k_col publishes its coefficients ahead of the record
   bool adaptSparse = true;    // CHS_ADAPT_SPARSE (chs_fast_rearm)
   long long csHost = -1;      // the device's computed_steps as the host can follow it (prepare / set_state / end of a call, +1 per
                               // issued step): lets the adaptive path issue the step-size machinery only on the steps whose rule

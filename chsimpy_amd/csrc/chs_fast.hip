@@ -120,6 +120,9 @@ int chs_fast_init(Engine* E) {
 int chs_fast_rearm(Engine* E) {
   E->fusedAdapt = E->adaptOk && getenv("CHS_ADAPT_SWEEP") == nullptr;
   { const char* e = getenv("CHS_ADAPT_SPARSE"); E->adaptSparse = !(e && e[0] == '0'); }   // (read when an engine is taken into use)
+  // (the coefficients of a firing step published ahead of the record, chs_tail.h: measured equal -- what a gated k_col pays is its
+  // own check of the gate, not the wait for the decision -- so it stays an experiment switch: CHS_GATE_EARLY=1)
+  { const char* e = getenv("CHS_GATE_EARLY"); E->gateEarly = (e && e[0] == '1'); }
   if (E->dc.adaptive_time && E->fusedAdapt && !E->dPartColRows)
     CHS_HIP(hipMalloc(&E->dPartColRows, E->esz * (size_t)E->nRowBlocks * E->N));
   if (E->partSet[0][0]) {
@@ -346,6 +349,8 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   const bool quiet = !fires && fa && E->dc.full_sim && !(E->dc.time_limit_s > 0.0);
   E->tailDeferred = true;
   E->tailGated = gate && !quiet;
+  // ... and one whose rule does fire, with nothing else armed, lets the tiles have their coefficients early (chs_tail.h)
+  E->tailEarly = E->tailGated && fires && fa && E->dc.full_sim && !(E->dc.time_limit_s > 0.0) && E->csHost >= 0 && E->adaptSparse && E->gateEarly;
   E->tailSet = E->parity;
   E->parity ^= 1;
   return CHS_OK;

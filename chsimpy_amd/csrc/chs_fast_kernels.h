@@ -1625,6 +1625,7 @@ struct Launch {
           if (E->tailGated) {
             ta.gate = 1; ta.seq = ++E->gateSeq;
             if (E->testGateWithhold) { ta.withhold = 1; ta.gate_spins = 1 << 10; }
+            ta.early = E->tailEarly ? 1 : 0;
           }
         } else if (E->preRider) {
           ta = chs_tail_args(E, -1, 1);

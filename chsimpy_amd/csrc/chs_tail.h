@@ -79,6 +79,8 @@ struct TailArgs {
   unsigned long long seq = 0;     // ... under this sequence number (DevState::decided)
   int gate_spins = 1 << 20;       // polls (s_sleep 16 between them, ~1 us each) before a waiting workgroup gives up
   int withhold = 0;               // test hook (CHS_TEST_GATE_WITHHOLD): the decision is never published
+  int early = 0;                  // gated for the adaptive step's sake alone (no stop rule armed): the coefficients of the coming
+                                  // step are published as soon as they are known, ahead of the record (step_tail_body)
   int pre_only = 0;  // first step of a call: no record yet, only the time-step control of the coming step
   int reverse = 0;  // (k_col rider, not a tail input) walk the column tiles in descending order this step
   DevConsts dc;
@@ -117,6 +119,35 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
   if (tid == 0) {
     loc = *st;
     if (!ta.pre_only) Ra = ta.partRa[0];
+  }
+  // EARLY DECISION.  When the launch is gated only because the step-size rule fires (full_sim, no time limit: nothing but
+  // lam1 / lam2 of the coming step is what the tiles wait for), those two are a function of the state and of the column
+  // minimum alone -- a few dozen numbers.  They are computed and published HERE, in front of the record's reductions (the
+  // partial sums of thousands of workgroups, four edge rows of U: ~28 us under a streaming launch, where the tiles reach the
+  // gate after ~12 us); the regular pre_update below arrives at the same two values bit for bit (same function, same inputs)
+  // and writes them again with the rest of the state.  A NaN found later stops the run one kernel later, as it does for a
+  // fixed time step (the field is unspecified then either way).
+  bool published = false;
+  if (ta.early && ta.gate && adapt && !ta.pre_only) {
+    double m = 1.0e300;
+    for (int i = tid; i < ta.nColMin; i += THREADS) m = fmin(m, ta.partColMin[i]);
+    m = wave_min(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < NW; ++w) m = fmin(m, red[w]);
+      DevState e = loc;
+      pre_update(dc, &e, 0.0, true, m);
+      st->lam1 = e.lam1; st->lam2 = e.lam2;
+      if (!ta.withhold) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&st->decided, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();   // (`red` is used again below)
+    published = true;
   }
   if (ta.pre_only) {
     // sum(mu^2) of the entry kernel -> L2 and the time bookkeeping of the first step (k_pre's work; fixed
@@ -237,7 +268,7 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
     st->computed_steps = loc.computed_steps; st->rows_written = loc.rows_written;
     st->skip_check = loc.skip_check; st->stop_reason = loc.stop_reason; st->nan_flag = loc.nan_flag;
     st->halt = loc.halt;
-    if (ta.gate && !ta.withhold) {
+    if (ta.gate && !ta.withhold && !published) {
       // everything above becomes visible at agent scope before the sequence number does: the waiting
       // workgroups (any CU, any XCD) read halt / lam1 / lam2 with agent-scope (L1-bypassing) loads behind it.
       // The explicit waits stand on both sides of the write-back: the state stores have left this wavefront
@@ -278,7 +309,14 @@ __device__ __forceinline__ int gate_wait(DevState* __restrict__ st, unsigned lon
     // ONE agent-scope acquire in the polling lane, once per workgroup and step, behind the matched poll: the payload
     // loads below are ordered behind the poll by the memory model, not by what gfx950 happens to do with sc1 loads
     // (gated modes only -- stop rules armed or an adaptive step)
+#ifndef CHS_GATE_ACQUIRE
+#define CHS_GATE_ACQUIRE 1
+#endif
+#if CHS_GATE_ACQUIRE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    asm volatile("" ::: "memory");
+#endif
     const int halt = __hip_atomic_load(&st->halt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     box[0] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&st->lam1), __ATOMIC_RELAXED,
                                                                __HIP_MEMORY_SCOPE_AGENT));
