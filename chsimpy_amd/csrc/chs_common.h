@@ -46,7 +46,7 @@ struct DevState {
   // that launch wait for it in front of their spectral stage.  gate_timeout: a wait gave up (never seen).
   unsigned long long decided;
   int gate_timeout;
-  int pad_;
+  int colmin_ticket;      // arrivals of k_colmin_slices' blocks when the last of them decides the coming step's coefficients
 };
 
 // Read-only scalars, passed to kernels by value.
@@ -226,6 +226,7 @@ struct Engine {
   bool hat_valid = false;  // dHat matches dU's history (CHS_STEP_CARRY_HAT)
   bool resident = false;   // ... and T1 / partMu hold the row transform of EnergieEut(U) and its sum of squares: the
                            // next call continues without an entry pass (the last fused step left them, chs_fast_step)
+  bool lamByColmin = true;    // CHS_LAM_BY_COLMIN (chs_fast_rearm): the reduction's last block sets the coming step's coefficients
   bool gateEarly = false;     // CHS_GATE_EARLY=1 (chs_fast_rearm): experiment, measured equal
   bool tailEarly = false;     // the gated bookkeeping of the coming k_col publishes its coefficients ahead of the record
   bool adaptSparse = true;    // CHS_ADAPT_SPARSE (chs_fast_rearm)
@@ -331,7 +332,7 @@ enum {
 int chs_launch_mu(Engine* E);                 // dU -> dMU, partials
 int chs_launch_mu_colsums(Engine* E, int cs_offset);
 int chs_fast_rearm(Engine* E);
-int chs_launch_colmin_rows(Engine* E, int cs_offset);  // min over the columns of sum(dPartColRows)  // dU -> column-sum minimum of the adaptive-step integrand only
+int chs_launch_colmin_rows(Engine* E, int cs_offset, bool decide = false);  // min over the columns of sum(dPartColRows)  // dU -> column-sum minimum of the adaptive-step integrand only
 struct TailArgs;
 TailArgs chs_tail_args(const Engine* E, int set, int do_pre);  // set < 0: the current partial-sum pointers
 int chs_launch_step_tail(Engine* E, int do_pre);  // fused pipeline: record of step s + time-step control of step s+1

@@ -123,6 +123,7 @@ int chs_fast_rearm(Engine* E) {
   // (the coefficients of a firing step published ahead of the record, chs_tail.h: measured equal -- what a gated k_col pays is its
   // own check of the gate, not the wait for the decision -- so it stays an experiment switch: CHS_GATE_EARLY=1)
   { const char* e = getenv("CHS_GATE_EARLY"); E->gateEarly = (e && e[0] == '1'); }
+  { const char* e = getenv("CHS_LAM_BY_COLMIN"); E->lamByColmin = !(e && e[0] == '0'); }
   if (E->dc.adaptive_time && E->fusedAdapt && !E->dPartColRows)
     CHS_HIP(hipMalloc(&E->dPartColRows, E->esz * (size_t)E->nRowBlocks * E->N));
   if (E->partSet[0][0]) {
@@ -335,10 +336,14 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   }
   chs_slot_end(E, SLOT_INV);
   if (rc) return rc;
+  // A firing step with nothing else armed: the reduction's last block works out the coming step's coefficients itself
+  // (k_colmin_slices, `decide`), so the next k_col needs no gate either -- its tiles read them from the state as ever
+  const bool lam_by_colmin = !last && fa && fires && E->csHost >= 0 && E->adaptSparse && E->lamByColmin && E->dc.full_sim &&
+                             !(E->dc.time_limit_s > 0.0) && !E->timer.on;
   if (!last && E->dc.adaptive_time && (fires || !fa)) {
     // column sums of the adaptive-step integrand of the NEXT step (solver.py:183); the record of
     // this step has not advanced computed_steps yet, hence the offset
-    if ((rc = fa ? chs_launch_colmin_rows(E, 1) : chs_launch_mu_colsums(E, 1))) return rc;
+    if ((rc = fa ? chs_launch_colmin_rows(E, 1, lam_by_colmin) : chs_launch_mu_colsums(E, 1))) return rc;
   }
   // Stop rules armed (energy rule, time limit) or an adaptive time step: the bookkeeping still rides in the
   // next k_col, whose other workgroups wait for its decision in front of their first global write (gated
@@ -346,7 +351,7 @@ int chs_fast_step(Engine* E, bool first, bool last) {
   const bool gate = !defer && !E->timer.on && E->partSet[0][0] != nullptr;
   if (last || (!defer && !gate)) return chs_launch_step_tail(E, last ? 0 : 1);
   // (an adaptive step whose rule does not fire decides nothing the next k_col needs, unless a stop rule is armed)
-  const bool quiet = !fires && fa && E->dc.full_sim && !(E->dc.time_limit_s > 0.0);
+  const bool quiet = (!fires || lam_by_colmin) && fa && E->dc.full_sim && !(E->dc.time_limit_s > 0.0);
   E->tailDeferred = true;
   E->tailGated = gate && !quiet;
   // ... and one whose rule does fire, with nothing else armed, lets the tiles have their coefficients early (chs_tail.h)

@@ -493,7 +493,7 @@ int chs_launch_mu(Engine* E) {
   return CHS_OK;
 }
 
-static int launch_colmin(Engine* E, const void* rows, bool rows_f32, int nRows, int cs_offset);
+static int launch_colmin(Engine* E, const void* rows, bool rows_f32, int nRows, int cs_offset, bool decide = false);
 
 int chs_launch_mu_colsums(Engine* E, int cs_offset) {
   chs_slot_begin(E, SLOT_MISC);
@@ -557,9 +557,14 @@ __global__ __launch_bounds__(PW_THREADS) void k_colsum_slices(const PT* __restri
     slices[(size_t)blockIdx.y * N + c] = t;
   }
 }
+// `decide` (the fused pipeline with nothing armed that a tail would have to decide: chs_fast_step): the block that finishes
+// last also takes the minimum over the blocks and works out the coming step's coefficients lam1 / lam2 -- the step-size rule of
+// solver.py:184-193 is a function of the current delt and of this minimum alone -- so that the next k_col finds them in the
+// state when it starts and needs NO gate; the riding bookkeeping arrives at the same values (same function, same inputs) and
+// writes them again with the rest of the state.  Arrival ticket in the state, release / acquire at agent scope.
 __global__ __launch_bounds__(PW_THREADS) void k_colmin_slices(const double* __restrict__ slices, int N,
-                                                              const DevState* __restrict__ st, int adaptive,
-                                                              double* __restrict__ partColMin, int cs_offset) {
+                                                              DevState* __restrict__ st, int adaptive,
+                                                              double* __restrict__ partColMin, int cs_offset, DevConsts dc, int decide) {
   __shared__ double scratch[32];
   if (st->halt) return;
   const long long cs = st->computed_steps + cs_offset;
@@ -575,11 +580,28 @@ __global__ __launch_bounds__(PW_THREADS) void k_colmin_slices(const double* __re
     for (int b = 0; b < CS_SLICES; ++b) s += x[b];
   }
   const double m = block_min(s, scratch);
-  if (threadIdx.x == 0) partColMin[blockIdx.x] = m;
+  if (threadIdx.x == 0) {
+    partColMin[blockIdx.x] = m;
+    if (decide) {
+      __threadfence();   // (release: this block's minimum is visible before its arrival is)
+      const int arrived = atomicAdd(&st->colmin_ticket, 1);
+      if (arrived == (int)gridDim.x - 1) {
+        __threadfence(); // (acquire: the other blocks' minima)
+        double mm = 1.0e300;
+        for (int b = 0; b < (int)gridDim.x; ++b)
+          mm = fmin(mm, __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&partColMin[b]),
+                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        DevState e = *st;
+        pre_update(dc, &e, 0.0, true, mm);
+        st->lam1 = e.lam1; st->lam2 = e.lam2;
+        st->colmin_ticket = 0;   // (for the next launch: kernel boundaries order it)
+      }
+    }
+  }
 }
 
 // partColMin[0 .. nColMinBlocks) <- block minima of the column sums of rows[nRows][N] (doubles, or floats: rows_f32)
-static int launch_colmin(Engine* E, const void* rows, bool rows_f32, int nRows, int cs_offset) {
+static int launch_colmin(Engine* E, const void* rows, bool rows_f32, int nRows, int cs_offset, bool decide) {
   if (!E->dColSlices) CHS_HIP(hipMalloc(&E->dColSlices, sizeof(double) * (size_t)CS_SLICES * E->N));
   const dim3 g1((E->N + CS_COLS - 1) / CS_COLS, CS_SLICES);
   const bool stream = chs_grid_exceeds_cache((size_t)E->N, E->dtype == CHS_F32 ? 4 : 8);
@@ -591,14 +613,14 @@ static int launch_colmin(Engine* E, const void* rows, bool rows_f32, int nRows, 
     else k_colsum_slices<double, false><<<g1, PW_THREADS, 0, E->stream>>>((const double*)rows, nRows, E->N, E->dState, E->dc.adaptive_time, E->dColSlices, cs_offset);
   }
   k_colmin_slices<<<E->nColMinBlocks, PW_THREADS, 0, E->stream>>>(E->dColSlices, E->N, E->dState, E->dc.adaptive_time,
-                                                                  E->dPartColMin, cs_offset);
+                                                                  E->dPartColMin, cs_offset, E->dc, decide ? 1 : 0);
   E->nColMinCur = E->nColMinBlocks;
   return CHS_OK;
 }
 
-int chs_launch_colmin_rows(Engine* E, int cs_offset) {
+int chs_launch_colmin_rows(Engine* E, int cs_offset, bool decide) {
   chs_slot_begin(E, SLOT_MISC);
-  const int rc = launch_colmin(E, E->dPartColRows, E->dtype == CHS_F32, E->nRowBlocks, cs_offset);
+  const int rc = launch_colmin(E, E->dPartColRows, E->dtype == CHS_F32, E->nRowBlocks, cs_offset, decide);
   chs_slot_end(E, SLOT_MISC);
   if (rc) return rc;
   CHS_HIP(hipGetLastError());
