@@ -85,7 +85,7 @@ __global__ __launch_bounds__(PW_THREADS) void k_pre(DevConsts dc, DevState* __re
 // ---------------------------------------------------------------------------
 __global__ void k_call_begin(DevConsts dc, DevState* __restrict__ st) {
 #pragma clang fp contract(off)
-  st->halt = 0; st->nan_flag = 0; st->rows_written = 0; st->gate_timeout = 0;
+  st->halt = 0; st->nan_flag = 0; st->rows_written = 0; st->gate_timeout = 0; st->colmin_ticket = 0;
   st->delt_coef = dc.delt0;
   const double lam1 = dc.delt0 / dc.delx2;
   st->lam1 = lam1;
@@ -583,10 +583,14 @@ __global__ __launch_bounds__(PW_THREADS) void k_colmin_slices(const double* __re
   if (threadIdx.x == 0) {
     partColMin[blockIdx.x] = m;
     if (decide) {
-      __threadfence();   // (release: this block's minimum is visible before its arrival is)
+      // release: this block's minimum is visible at agent scope before its arrival is (explicit waits on both sides of the
+      // write-back, as in step_tail_body: hipcc may drop the fence's own wait, cdna_hip_programming.md Guideline 16)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int arrived = atomicAdd(&st->colmin_ticket, 1);
       if (arrived == (int)gridDim.x - 1) {
-        __threadfence(); // (acquire: the other blocks' minima)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other blocks' minima (read with agent-scope loads below)
         double mm = 1.0e300;
         for (int b = 0; b < (int)gridDim.x; ++b)
           mm = fmin(mm, __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&partColMin[b]),
