@@ -392,3 +392,45 @@ def test_reference_default_configuration_runs_to_its_energy_stop(gpu):
              f"GPU wall {dt:.2f} s")
     assert dt < 10.0
     sim.solver.close()
+
+
+@pytest.mark.parametrize("N,dtype,tol", [(1024, 'float64', 1e-9), (2048, 'float32', 2e-4)])
+def test_adaptive_chunks_of_every_alignment_seeded_at_step_499(gpu, N, dtype, tol):
+    """The adaptive path issues its step-size machinery only on the steps whose rule fires (every second one beyond
+    step 500, solver.py:177) -- the host follows the device's step counter to know which (Engine::csHost: prepare /
+    chs_set_state / end of a call, +1 per issued step) -- and on those steps the reduction's last block sets the coming
+    step's coefficients, so that no k_col is gated.  Calls of 1, 2, 1, 3, 1, 1, 4 and 2 steps from a counter seeded at
+    499 put a call boundary on every alignment of that pattern (a call's first step takes the sweep kernel and k_pre
+    instead, its last step the separate tail), each call reloads the coefficients of params.delt (the resume quirk,
+    solver.py:154-155); the delt history, the record and U against the oracle's chunks."""
+    chunks = (1, 2, 1, 3, 1, 1, 4, 2)
+    kw = dict(adaptive_time=True, delt_max=4.9e-7 / N)
+    s = chsimpy_amd.Solver(make(N, 10 ** 6, 'fast', dtype=dtype, **kw))
+    s.prepare()
+    eng = s._engine
+    st = eng.get_state()
+    st.computed_steps = 499
+    st.skip_check = 1
+    eng.set_state(st)
+    o = orc.OracleSolver(orc.make_params(N, 10 ** 6, **kw))
+    o.prepare()
+    o.computed_steps = 499
+    o.skip_check = True
+    got = []
+    for c in chunks:
+        rows, rc = eng.step_n(c)
+        assert rc == 0 and rows.shape == (c, 9)
+        got.append(rows)
+        o.solve_or_resume(c)
+    rows = np.vstack(got)
+    to = o.timedata.data()[1:]
+    assert rows.shape == to.shape == (sum(chunks), 9)
+    assert np.array_equal(rows[:, 0], to[:, 0]) and rows[0, 0] == 499
+    assert len(np.unique(to[:, 8])) >= 4                      # the rule fired several times, on both sides of call boundaries
+    errs = {c: relerr(rows[:, c], to[:, c]) for c in (1, 2, 4, 8)}
+    eu = relerr(eng.get_U(), o.U)
+    log_line(f"N={N} {dtype} adaptive, chunks {chunks} from step 499: delt {errs[8]:.3e} E {errs[1]:.3e} E2 {errs[2]:.3e} U {eu:.3e}")
+    assert errs[8] < (1e-9 if dtype == 'float64' else 1e-4), errs
+    assert errs[1] < (1e-9 if dtype == 'float64' else 1e-5) and errs[4] < (1e-9 if dtype == 'float64' else 1e-4), errs
+    assert eu < tol, eu
+    s.close(fetch_U=False)
