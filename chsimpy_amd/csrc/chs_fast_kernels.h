@@ -1321,6 +1321,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
     }
     __syncthreads();
     if constexpr (MODE == MODE_STEP) STAMP(1, 1);
+#ifndef CHS_GATE_EARLY_POLL
+#define CHS_GATE_EARLY_POLL 0   // (measured equal in energy-stop mode: 0.9932 / 0.9954 with it off; experiment switch)
+#endif
+    // (gated launches: the polling lane asks for the sequence word HERE; the answer is looked at behind the passes)
+    [[maybe_unused]] unsigned long long early_seq = ~0ull;
+    if constexpr (MODE == MODE_STEP && CHS_GATE_EARLY_POLL != 0) {
+      if (ta.gate && threadIdx.x == 0) early_seq = __hip_atomic_load(&st->decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if constexpr (PRE0) fwd_passes<C, TW0POW>(z, scr, tbp, l, [&]() {
       const int hp = hat_pair_index<C>(0, fc_opaque(l));
       s0.h01 = ldc_hint<T, HAT_NT_LD>(hcol, hp);
@@ -1334,7 +1342,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void k_col(const typename C::T*
       // decision here: stopped -> leave hat_U, T and the partial sums as the previous step left them
       // (run_steps rebuilds U from hat_U); otherwise take this step's coefficients from it.
       if (ta.gate) {
-        if (gate_wait(st, ta.seq, ta.gate_spins, red, lam1, lam2)) return;
+        if (gate_wait(st, ta.seq, ta.gate_spins, red, lam1, lam2, early_seq)) return;
       }
     }
   }

@@ -292,11 +292,13 @@ __device__ __forceinline__ void step_tail_body(const TailArgs& ta, DevState* __r
 // drained them, released at agent scope and then stored the sequence number.  The consumer's polling lane polls
 // relaxed, issues ONE agent-scope acquire once the poll has matched and then reads the payload itself (agent-scope
 // loads); the other wavefronts get the values through LDS behind the workgroup barrier.  `box` = 4 doubles of LDS.
+// `early` = what the polling lane read from the sequence word in front of the forward passes (a load whose round trip ran under
+// them): when it already shows this launch's number -- every workgroup but those of the first round -- no poll is needed at all.
 __device__ __forceinline__ int gate_wait(DevState* __restrict__ st, unsigned long long seq, int spins, double* box,
-                                         double& lam1, double& lam2) {
+                                         double& lam1, double& lam2, unsigned long long early = ~0ull) {
   if (threadIdx.x == 0) {
     int it = 0, tmo = 0;
-    while (__hip_atomic_load(&st->decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+    while (early != seq && __hip_atomic_load(&st->decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
       __builtin_amdgcn_s_sleep(16);
       // (a sibling that has already given up spares the others the full wait)
       if (++it > spins || ((it & 63) == 0 && __hip_atomic_load(&st->gate_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
