@@ -465,7 +465,10 @@ def main():
             'energies_last_step': energies,
         }
         if world == 1 and not a.no_extras and N == 4096 and esz == 8 and not a.energy_stop and eng.engine == 'fast':
-            out['config'].update(extra_figures(a, eng, torch, device))
+            try:
+                out['config'].update(extra_figures(a, eng, torch, device))
+            except Exception as e:   # (the extra figures must never cost the line itself)
+                out['config']['extras_error'] = f'{type(e).__name__}: {e}'[:300]
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(N, a.cpu_steps)
         elif world == 1:

@@ -80,6 +80,21 @@ def build_hip(force=False, verbose=False, out=None, extra=None):
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if not force and is_current(out, extra):
         return out
+    # One builder at a time: several ranks of one launch may find a stale library at once (torch.distributed.run starts
+    # them together); the others wait for the lock and then find the library current.
+    import fcntl
+    with open(os.path.join(LIBDIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and is_current(out, extra):
+                return out
+            return _build_locked(out, extra, force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(out, extra, force, verbose):
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
     hipcc = os.environ.get('HIPCC', 'hipcc')
     objdir = os.path.join(LIBDIR, 'obj' if out == LIB else 'obj_' + os.path.basename(out))
