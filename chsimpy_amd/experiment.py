@@ -283,7 +283,8 @@ def main(argv=None):
     p = Parameters()
     p.N, p.ntmax, p.full_sim, p.kappa_tilde = a.N, a.ntmax, a.full_sim, a.kappa_tilde
     p.no_gui, p.export_csv, p.Uinit_file = True, a.export_csv, a.Uinit_file
-    p.device = local_rank
+    # (CHS_SAME_GPU=1: every rank on device 0 -- rehearsing the multi-rank path with real device work on a one-GPU box)
+    p.device = 0 if os.environ.get('CHS_SAME_GPU') == '1' else local_rank
     p.file_id = utils.get_or_create_file_id(a.file_id)
     ep = ExperimentParams()
     ep.runs, ep.independent, ep.A_source, ep.A_seed = a.runs, a.independent, a.A_source, a.A_seed
